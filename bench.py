@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the SAD disparity hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-gpu F]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+          --master-port P bench.py --gpus N --steps K --warmup W)
+
+Workload (BASELINE.json configs[2]/[3]): 1920x1080 synthetic grayscale pairs, block 9, Dmax 64.
+A "step" = one pass of the hot path over this rank's shard of the frame stream: F independent
+pairs (default 128 = 1024 / 8, config 4's per-GPU share), device-resident (generated in HBM
+before the timed region), one batched launch on torch's current stream through the C ABI.
+Frames shard round-robin across ranks with no data-path collective (weak scaling); the two
+parameters are broadcast from rank 0 over RCCL.
+
+Prints ONE JSON line on rank 0: metric = stereo pairs/s (whole job), plus ms/frame, the HBM
+roofline object for the disparity kernel, candidate evaluations/s, and the CPU baseline
+(oracle "port" of pkg/despair timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+W, H, BLOCK, MAXDISP = 1920, 1080, 9, 64
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-gpu", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=0, help="sadhip flags (2 = force generic kernel)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import steroscopic_hardware_amd as sha
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    dist = None
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    # parameters: rank 0 decides, everyone else receives them (2 x int32 over RCCL/xGMI)
+    params = torch.tensor([BLOCK, MAXDISP] if rank == 0 else [0, 0], dtype=torch.int32, device=dev)
+    if dist is not None:
+        dist.broadcast(params, src=0)
+    block, maxdisp = (int(v) for v in params.cpu())
+
+    F = args.frames_per_gpu
+    seeds = [1000 + rank + world * k for k in range(F)]          # frame i -> GPU i mod G
+    Ls, Rs = [], []
+    for c in range(0, F, 16):                                     # generate in HBM, in chunks
+        l, r = sha.synth.synth_batch_torch(seeds[c:c + 16], W, H, dev)
+        Ls.append(l); Rs.append(r)
+    Ls = torch.cat(Ls); Rs = torch.cat(Rs)
+    out = torch.empty_like(Ls)
+    ctx = sha.capi.Context(local, W, H, 1)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ctx.disparity_dev(Ls, Rs, out, block, maxdisp, args.flags, stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:                                            # HIP events on the launch stream
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    launch_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    avg_launch_ms = sum(launch_ms) / len(launch_ms)
+
+    # single-pair latency (ms/frame of one 1080p pair on an otherwise idle GPU)
+    one_ms = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        ctx.disparity_dev(Ls[:1], Rs[:1], out[:1], block, maxdisp, args.flags, stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        one_ms.append(e0.elapsed_time(e1))
+    one_ms = sorted(one_ms)[len(one_ms) // 2]
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_frames = F * world * args.steps
+    alg_bytes_per_launch = 3 * W * H * F                          # read 2WH + write WH per pair
+    cands = sha.synth.candidates_per_pair(W, H, block, maxdisp)
+    achieved_gbps = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    res = {
+        "metric": "stereo pairs/sec, 1920x1080 gray, block=9 Dmax=64",
+        "value": total_frames / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]/[3]: {W}x{H} synthetic pairs (splitmix64, seeds 1000+i), "
+                               f"block={block}, Dmax={maxdisp}; {F} device-resident pairs per GPU per step, "
+                               "frames sharded round-robin, params broadcast only",
+                   "frames_per_gpu_per_step": F, "width": W, "height": H, "block": block, "maxdisp": maxdisp,
+                   "kernel_kind": sha.capi.kernel_kind(W, H, block, maxdisp, args.flags)},
+        "ms_per_frame": avg_launch_ms / F,
+        "ms_per_frame_single_pair_latency": one_ms,
+        "gcand_per_s": cands * F / (avg_launch_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel_avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                     "note": "path is integer-VALU bound (SURVEY 8d); see gcand_per_s and DESIGN.md"},
+    }
+
+    if not args.no_cpu_baseline:
+        import oracle
+        nthr = args.cpu_threads or min(16, os.cpu_count() or 1)
+        L0, R0 = Ls[0].cpu().numpy(), Rs[0].cpu().numpy()
+        t1 = time.perf_counter()
+        cpu = oracle.disparity_rows_mt(L0, R0, block, maxdisp, 0, H, nthr)      # one full pair
+        cpu_s = time.perf_counter() - t1
+        ok = bool(np.array_equal(cpu, out[0].cpu().numpy()))
+        res["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "pairs/s", "cores": nthr, "kind": "port",
+                               "sample": f"1 full {W}x{H} pair (frame seed 1000), literal restatement of "
+                                         f"pkg/despair sad.go:55-94 in C, {nthr} threads over output.go row bands, "
+                                         f"{cpu_s:.2f} s wall", "gpu_output_matches": ok}
+        if not ok:
+            res["parity_error"] = "GPU frame 0 differs from the CPU oracle"
+    print(json.dumps(res))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,233 @@
+"""ctypes binding of the C ABI in include/sadhip.h (lib/libsadhip.so).
+
+This is the Python counterpart of the cgo stub in INTEGRATION.md: same entry points, same
+argument meaning.  numpy arrays travel as host pointers; torch CUDA tensors travel as raw
+device pointers (``tensor.data_ptr()``) into the ``*_dev_*`` entry point -- torch is plumbing
+for device memory and streams only.
+
+No fallback: if the shared library is missing or fails to load, importing this module's
+``lib()`` raises; if there is no GPU, every compute call raises SadHipError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsadhip.so")
+
+OK = 0
+ERR_NULL, ERR_DIMS, ERR_STRIDE, ERR_BLOCK, ERR_MAXDISP, ERR_REGION, ERR_BATCH, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = range(1, 12)
+FLAG_RAW = 1
+FLAG_FORCE_GENERIC = 2
+MAX_BLOCK = 255
+MAX_MAXDISP = 4096
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+
+# every symbol include/sadhip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sadhip_abi_version": (C.c_int, []),
+    "sadhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sadhip_status_string": (C.c_char_p, [C.c_int]),
+    "sadhip_last_error": (C.c_char_p, []),
+    "sadhip_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sadhip_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "sadhip_ctx_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "sadhip_disparity_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int]),
+    "sadhip_disparity_region_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sadhip_disparity_batch_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
+                                            C.POINTER(C.c_void_p), C.c_int]),
+    "sadhip_disparity_dev_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
+                                          C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "sadhip_sad_windows_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sadhip_gray_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "sadhip_disparity_rgba_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int]),
+    "sadhip_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sadhip_kernel_kind": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
+}
+
+_LIB = None
+
+
+class SadHipError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__(f"sadhip status {status}: {detail}")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of lib/libsadhip.so (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", csrc], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """Loads libsadhip.so; raises (never falls back) when it is absent or lacks a symbol."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)          # AttributeError if the ABI symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = l
+    return _LIB
+
+
+def _check(status):
+    if status != OK:
+        raise SadHipError(status, (lib().sadhip_last_error() or b"").decode(errors="replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().sadhip_device_count(C.byref(n)))
+    return n.value
+
+
+def kernel_kind(w, h, block, maxdisp, flags=0):
+    return lib().sadhip_kernel_kind(w, h, block, maxdisp, flags)
+
+
+def _img(a, name):
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.ndim != 2 or a.strides[1] != 1 or a.strides[0] < 0:
+        raise TypeError(f"{name}: expected a 2-D uint8 numpy array with unit column stride")
+    return a
+
+
+class Context:
+    """Per-device context (sadhip_ctx).  Use as a context manager or call close()."""
+
+    def __init__(self, device=0, max_w=1920, max_h=1080, max_batch=1):
+        self._h = C.c_void_p()
+        _check(lib().sadhip_ctx_create(device, max_w, max_h, max_batch, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().sadhip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer entry points ---------------------------------------------------------
+    def disparity(self, left, right, block, maxdisp, flags=0, out=None):
+        _img(left, "left"), _img(right, "right")
+        if left.shape != right.shape:
+            raise SadHipError(ERR_DIMS, "left/right shape mismatch")
+        h, w = left.shape
+        if out is None:
+            out = np.empty((h, w), np.uint8)
+        _img(out, "out")
+        _check(lib().sadhip_disparity_u8(self._h, left.ctypes.data, right.ctypes.data, w, h,
+                                         left.strides[0], right.strides[0], block, maxdisp, flags,
+                                         out.ctypes.data, out.strides[0]))
+        return out
+
+    def disparity_region(self, left, right, block, maxdisp, region, flags=0):
+        _img(left, "left"), _img(right, "right")
+        if left.shape != right.shape:
+            raise SadHipError(ERR_DIMS, "left/right shape mismatch")
+        h, w = left.shape
+        x0, y0, x1, y1 = region
+        out = np.empty((max(y1 - y0, 0), max(x1 - x0, 0)), np.uint8)
+        _check(lib().sadhip_disparity_region_u8(self._h, left.ctypes.data, right.ctypes.data, w, h,
+                                                left.strides[0], right.strides[0], block, maxdisp, flags,
+                                                x0, y0, x1, y1, out.ctypes.data if out.size else None))
+        return out
+
+    def disparity_batch(self, lefts, rights, block, maxdisp, flags=0):
+        n = len(lefts)
+        assert len(rights) == n
+        if n == 0:
+            _check(lib().sadhip_disparity_batch_u8(self._h, 0, None, None, 1, 1, 1, 1, block, maxdisp, flags, None, 1))
+            return []
+        h, w = lefts[0].shape
+        ls, rs = lefts[0].strides[0], rights[0].strides[0]
+        for a in list(lefts) + list(rights):
+            _img(a, "frame")
+            assert a.shape == (h, w)
+        assert all(a.strides[0] == ls for a in lefts) and all(a.strides[0] == rs for a in rights)
+        outs = [np.empty((h, w), np.uint8) for _ in range(n)]
+        pa = (C.c_void_p * n)(*[a.ctypes.data for a in lefts])
+        pb = (C.c_void_p * n)(*[a.ctypes.data for a in rights])
+        po = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
+        _check(lib().sadhip_disparity_batch_u8(self._h, n, pa, pb, w, h, ls, rs, block, maxdisp, flags, po, w))
+        return outs
+
+    def sad_windows(self, left, right, block, queries):
+        _img(left, "left"), _img(right, "right")
+        q = np.ascontiguousarray(np.asarray(queries, dtype=np.int32).reshape(-1, 4))
+        out = np.zeros(len(q), np.int32)
+        _check(lib().sadhip_sad_windows_u8(self._h, left.ctypes.data, left.shape[1], left.shape[0], left.strides[0],
+                                           right.ctypes.data, right.shape[1], right.shape[0], right.strides[0],
+                                           block, len(q), q.ctypes.data if len(q) else None,
+                                           out.ctypes.data if len(q) else None))
+        return out
+
+    def gray(self, pix):
+        if not isinstance(pix, np.ndarray) or pix.dtype != np.uint8 or pix.ndim != 3 or pix.shape[2] not in (3, 4):
+            raise TypeError("pix: expected HxWx3 or HxWx4 uint8")
+        pix = np.ascontiguousarray(pix)
+        h, w, c = pix.shape
+        g = np.empty((h, w), np.uint8)
+        _check(lib().sadhip_gray_u8(self._h, pix.ctypes.data, c, w, h, pix.strides[0], g.ctypes.data, g.strides[0]))
+        return g
+
+    def disparity_rgba(self, left_pix, right_pix, block, maxdisp, flags=0):
+        left_pix = np.ascontiguousarray(left_pix); right_pix = np.ascontiguousarray(right_pix)
+        assert left_pix.shape == right_pix.shape and left_pix.dtype == np.uint8 and left_pix.ndim == 3
+        h, w, c = left_pix.shape
+        out = np.empty((h, w), np.uint8)
+        _check(lib().sadhip_disparity_rgba_u8(self._h, left_pix.ctypes.data, right_pix.ctypes.data, c, w, h,
+                                              left_pix.strides[0], right_pix.strides[0], block, maxdisp, flags,
+                                              out.ctypes.data, out.strides[0]))
+        return out
+
+    def last_timing(self):
+        k, t = C.c_float(0), C.c_float(0)
+        _check(lib().sadhip_last_timing(self._h, C.byref(k), C.byref(t)))
+        return k.value, t.value
+
+    # ---- device-resident entry point (torch CUDA tensors as raw pointers) --------------------
+    def disparity_dev(self, d_left, d_right, d_out, block, maxdisp, flags=0, stream=None):
+        """d_left/d_right/d_out: torch uint8 CUDA tensors of shape [n,h,w] (or [h,w]), row-contiguous.
+        Enqueues on ``stream`` (an int hipStream_t; default: torch's current stream) and returns."""
+        import torch
+        if d_left.dim() == 2:
+            d_left, d_right, d_out = d_left[None], d_right[None], d_out[None]
+        n, h, w = d_left.shape
+        for t in (d_left, d_right, d_out):
+            assert t.is_cuda and t.dtype == torch.uint8 and t.shape == (n, h, w) and t.stride(2) == 1
+        if stream is None:
+            stream = torch.cuda.current_stream(d_left.device).cuda_stream
+        _check(lib().sadhip_disparity_dev_u8(self._h, n, d_left.data_ptr(), d_right.data_ptr(),
+                                             d_left.stride(0), d_right.stride(0), w, h,
+                                             d_left.stride(1), d_right.stride(1), block, maxdisp, flags,
+                                             d_out.data_ptr(), d_out.stride(0), d_out.stride(1), stream))
+        return d_out

@@ -1,0 +1,169 @@
+// kernels_generic.hip -- the always-correct gfx950 kernels: generic disparity (any
+// BlockSize / MaxDisparity / image size), single-window SADs, gray conversion.
+//
+// The generic disparity kernel is the fallback for parameter sets the fast kernel
+// (kernels_fast.hip) does not cover, and an independent second implementation the tests
+// cross-check the fast kernel against.  One thread per output pixel; inputs are read
+// through L1/L2 (the whole 1080p pair is 4 MB: it lives in the 4 MiB-per-XCD L2 / 256 MiB
+// Infinity Cache), no LDS.  Arithmetic: u32, closed form of pkg/despair/sad.go:55-94 +
+// :205-244:
+//     dmax(x) = min(D, max(0, x - hs)),   window clipped to the image, L and R aligned.
+#include "sadhip_kernels.h"
+
+namespace sadhip {
+
+__global__ void __launch_bounds__(256)
+k_disparity_generic(Job j)
+{
+  // 64 x 4 pixel tiles: consecutive lanes -> consecutive x (coalesced row reads / u8 stores)
+  const int x = j.x0 + blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = j.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int f = blockIdx.z;
+  if (x >= j.x1 || y >= j.y1) return;
+
+  const uint8_t* __restrict__ L = j.left + (size_t)f * j.left_frame_stride;
+  const uint8_t* __restrict__ R = j.right + (size_t)f * j.right_frame_stride;
+  const int hs = j.block / 2;                                   // sad.go:209
+  const int wy0 = max(y - hs, 0), wy1 = min(y + hs + 1, j.h);   // sad.go:212-213
+  const int wx0 = max(x - hs, 0), wx1 = min(x + hs + 1, j.w);   // sad.go:214-215
+  const int dmax = min(j.maxdisp, max(0, x - hs));              // sad.go:64-67 + :217-218 folded
+
+  unsigned best_sad = 0xffffffffu;
+  int best = 0;
+  for (int d = 0; d <= dmax; ++d) {                             // sad.go:62
+    unsigned sad = 0;
+    for (int yy = wy0; yy < wy1; ++yy) {                        // sad.go:224
+      const uint8_t* lp = L + (size_t)(yy - j.row0) * j.lstride;
+      const uint8_t* rp = R + (size_t)(yy - j.row0) * j.rstride - d;
+      for (int xx = wx0; xx < wx1; ++xx) {                      // sad.go:230
+        int diff = (int)lp[xx] - (int)rp[xx];                   // sad.go:234-235
+        sad += (unsigned)(diff < 0 ? -diff : diff);             // sad.go:236-239
+      }
+    }
+    if (sad < best_sad) { best_sad = sad; best = d; }           // sad.go:79-81 (first minimum)
+  }
+  const int v = j.raw ? min(best, 255) : (best * 255) / j.maxdisp;   // sad.go:91-93
+  j.out[(size_t)f * j.out_frame_stride + (size_t)(y - j.oy) * j.ostride + (x - j.ox)] = (uint8_t)v;
+}
+
+hipError_t launch_generic(const Job& j, hipStream_t s)
+{
+  const int rw = j.x1 - j.x0, rh = j.y1 - j.y0;
+  if (rw <= 0 || rh <= 0 || j.n <= 0) return hipSuccess;
+  // grid.z is limited to 65535: split very large batches
+  for (int f0 = 0; f0 < j.n; f0 += 32768) {
+    Job jj = j;
+    jj.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
+    jj.left += (size_t)f0 * j.left_frame_stride;
+    jj.right += (size_t)f0 * j.right_frame_stride;
+    jj.out += (size_t)f0 * j.out_frame_stride;
+    dim3 grid((rw + 63) / 64, (rh + 3) / 4, jj.n);
+    hipLaunchKernelGGL(k_disparity_generic, grid, dim3(256), 0, s, jj);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SumAbsoluteDifferences (sad.go:205-244), literal: independent clamp of the right window
+// (:217-218), walk with the LEFT window's extent (:224,:230), early breaks when the right
+// window runs past right.Rect.Max (:225-227,:231-233).  One thread per query.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_sad_windows(const uint8_t* __restrict__ left, int lw, int lh, int lstride,
+              const uint8_t* __restrict__ right, int rw, int rh, int rstride,
+              int block, int n, const int32_t* __restrict__ q, int32_t* __restrict__ out)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const int leftX = q[4 * i + 0], leftY = q[4 * i + 1], rightX = q[4 * i + 2], rightY = q[4 * i + 3];
+  const int hs = block / 2;
+  const int leftMinY = max(leftY - hs, 0), leftMaxY = min(leftY + hs + 1, lh);
+  const int leftMinX = max(leftX - hs, 0), leftMaxX = min(leftX + hs + 1, lw);
+  const int rightMinY = max(rightY - hs, 0), rightMinX = max(rightX - hs, 0);
+  int sad = 0;
+  for (int ly = leftMinY; ly < leftMaxY; ++ly) {
+    const int ry = rightMinY + (ly - leftMinY);
+    if (ry >= rh) break;
+    for (int lx = leftMinX; lx < leftMaxX; ++lx) {
+      const int rx = rightMinX + (lx - leftMinX);
+      if (rx >= rw) break;
+      int diff = (int)left[(size_t)ly * lstride + lx] - (int)right[(size_t)ry * rstride + rx];
+      sad += diff < 0 ? -diff : diff;
+    }
+  }
+  out[i] = sad;
+}
+
+hipError_t launch_sad_windows(const uint8_t* left, int lw, int lh, int lstride,
+                              const uint8_t* right, int rw, int rh, int rstride,
+                              int block, int n, const int32_t* queries, int32_t* out, hipStream_t s)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_sad_windows, dim3((n + 63) / 64), dim3(64), 0, s,
+                     left, lw, lh, lstride, right, rw, rh, rstride, block, n, queries, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gray conversion: pkg/despair/gray.go:43-58 on an *image.NRGBA (channels == 4) or an opaque
+// 8-bit RGB source (channels == 3); identical to color.GrayModel.Convert
+// (pkg/camera/output.go:145,160).
+//   NRGBA.RGBA(): c16 = c8*0x101 * (a8*0x101) / 0xffff ;  Y = (19595r + 38470g + 7471b + 2^15) >> 24
+// 4 pixels per thread: one 16-byte load (RGBA) and one packed 4-byte store.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned gray_nrgba(unsigned px)
+{
+  const unsigned r8 = px & 0xff, g8 = (px >> 8) & 0xff, b8 = (px >> 16) & 0xff, a8 = px >> 24;
+  const unsigned a = a8 * 0x101u;
+  const unsigned r = r8 * 0x101u * a / 0xffffu;
+  const unsigned g = g8 * 0x101u * a / 0xffffu;
+  const unsigned b = b8 * 0x101u * a / 0xffffu;
+  return (19595u * r + 38470u * g + 7471u * b + (1u << 15)) >> 24;
+}
+
+__global__ void __launch_bounds__(256)
+k_gray(const uint8_t* __restrict__ pix, int channels, int w, int h, int stride,
+       uint8_t* __restrict__ gray, int gstride)
+{
+  const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int y = blockIdx.y;
+  if (x4 >= w || y >= h) return;
+  const uint8_t* row = pix + (size_t)y * stride;
+  uint8_t* grow = gray + (size_t)y * gstride;
+  unsigned v[4];
+  const int nn = min(4, w - x4);
+  if (channels == 4) {
+    if (nn == 4 && ((((size_t)row) + (size_t)x4 * 4) & 15) == 0) {
+      const uint4 p = *reinterpret_cast<const uint4*>(row + (size_t)x4 * 4);
+      v[0] = gray_nrgba(p.x); v[1] = gray_nrgba(p.y); v[2] = gray_nrgba(p.z); v[3] = gray_nrgba(p.w);
+    } else {
+      for (int k = 0; k < nn; ++k) {
+        const uint8_t* p = row + (size_t)(x4 + k) * 4;
+        v[k] = gray_nrgba((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));
+      }
+    }
+  } else {
+    for (int k = 0; k < nn; ++k) {
+      const uint8_t* p = row + (size_t)(x4 + k) * 3;
+      v[k] = gray_nrgba((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | 0xff000000u);
+    }
+  }
+  if (nn == 4 && ((((size_t)grow) + x4) & 3) == 0) {
+    *reinterpret_cast<unsigned*>(grow + x4) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+  } else {
+    for (int k = 0; k < nn; ++k) grow[x4 + k] = (uint8_t)v[k];
+  }
+}
+
+hipError_t launch_gray(const uint8_t* pix, int channels, int w, int h, int stride,
+                       uint8_t* gray, int gstride, hipStream_t s)
+{
+  if (w <= 0 || h <= 0) return hipSuccess;
+  dim3 grid((w + 1023) / 1024, h);
+  hipLaunchKernelGGL(k_gray, grid, dim3(256), 0, s, pix, channels, w, h, stride, gray, gstride);
+  return hipGetLastError();
+}
+
+}  // namespace sadhip

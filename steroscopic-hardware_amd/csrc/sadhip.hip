@@ -1,0 +1,524 @@
+// sadhip.hip -- C ABI (include/sadhip.h) over the gfx950 kernels.  Host side only:
+// argument validation, per-device context (device buffers, pinned staging, streams),
+// H2D / kernel / D2H pipelining.  No CPU compute fallback lives here.
+#include "../../include/sadhip.h"
+#include "sadhip_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+using namespace sadhip;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int status, const char* fmt, ...)
+{
+  va_list ap; va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+#define HIPTRY(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(SADHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+extern "C" const char* sadhip_last_error(void) { return g_err; }
+
+extern "C" const char* sadhip_status_string(int s)
+{
+  switch (s) {
+    case SADHIP_OK: return "ok";
+    case SADHIP_ERR_NULL: return "null pointer";
+    case SADHIP_ERR_DIMS: return "bad image dimensions";
+    case SADHIP_ERR_STRIDE: return "row stride smaller than width";
+    case SADHIP_ERR_BLOCK: return "bad block size";
+    case SADHIP_ERR_MAXDISP: return "bad max disparity";
+    case SADHIP_ERR_REGION: return "bad region";
+    case SADHIP_ERR_BATCH: return "bad batch size";
+    case SADHIP_ERR_NO_DEVICE: return "no usable HIP device";
+    case SADHIP_ERR_HIP: return "HIP runtime error";
+    case SADHIP_ERR_ARG: return "invalid argument";
+    case SADHIP_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int sadhip_abi_version(void) { return SADHIP_ABI_VERSION; }
+
+extern "C" int sadhip_device_count(int* count)
+{
+  if (!count) return fail(SADHIP_ERR_NULL, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(SADHIP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return SADHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Slot {            // one pipeline stage worth of buffers (one frame)
+  uint8_t *hL = nullptr, *hR = nullptr, *hO = nullptr;   // pinned host staging
+  uint8_t *dL = nullptr, *dR = nullptr, *dO = nullptr;   // device planes
+  hipStream_t stream = nullptr;
+  hipEvent_t k0 = nullptr, k1 = nullptr;                 // kernel begin / end
+};
+
+struct sadhip_ctx {
+  int device = 0;
+  int max_w = 0, max_h = 0, max_batch = 0;
+  size_t pitch = 0;            // bytes per row of the staging planes
+  size_t plane = 0;            // bytes per staging plane
+  static constexpr int kSlots = 2;
+  Slot slot[kSlots];
+  // scratch for sad_windows / gray (grown on demand)
+  void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
+  void* h_scratch = nullptr; size_t h_scratch_bytes = 0;
+  float last_kernel_ms = 0.f, last_total_ms = 0.f;
+  std::mutex mu;
+};
+
+static int ensure_scratch(sadhip_ctx* c, size_t dbytes, size_t hbytes)
+{
+  if (dbytes > c->d_scratch_bytes) {
+    if (c->d_scratch) HIPTRY(hipFree(c->d_scratch));
+    c->d_scratch = nullptr; c->d_scratch_bytes = 0;
+    HIPTRY(hipMalloc(&c->d_scratch, dbytes));
+    c->d_scratch_bytes = dbytes;
+  }
+  if (hbytes > c->h_scratch_bytes) {
+    if (c->h_scratch) HIPTRY(hipHostFree(c->h_scratch));
+    c->h_scratch = nullptr; c->h_scratch_bytes = 0;
+    HIPTRY(hipHostMalloc(&c->h_scratch, hbytes, hipHostMallocDefault));
+    c->h_scratch_bytes = hbytes;
+  }
+  return SADHIP_OK;
+}
+
+static void destroy_ctx(sadhip_ctx* c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (auto& s : c->slot) {
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.hL) (void)hipHostFree(s.hL);
+    if (s.hR) (void)hipHostFree(s.hR);
+    if (s.hO) (void)hipHostFree(s.hO);
+    if (s.dL) (void)hipFree(s.dL);
+    if (s.dR) (void)hipFree(s.dR);
+    if (s.dO) (void)hipFree(s.dO);
+    if (s.k0) (void)hipEventDestroy(s.k0);
+    if (s.k1) (void)hipEventDestroy(s.k1);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  }
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+  delete c;
+}
+
+extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch, sadhip_ctx** out)
+{
+  if (!out) return fail(SADHIP_ERR_NULL, "out is NULL");
+  *out = nullptr;
+  if (max_w <= 0 || max_h <= 0) return fail(SADHIP_ERR_DIMS, "max_w=%d max_h=%d", max_w, max_h);
+  if (max_batch < 1) return fail(SADHIP_ERR_BATCH, "max_batch=%d", max_batch);
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SADHIP_ERR_NO_DEVICE, "no HIP device");
+  if (device < 0 || device >= n) return fail(SADHIP_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
+  HIPTRY(hipSetDevice(device));
+
+  sadhip_ctx* c = new (std::nothrow) sadhip_ctx();
+  if (!c) return fail(SADHIP_ERR_NOMEM, "context allocation failed");
+  c->device = device; c->max_w = max_w; c->max_h = max_h; c->max_batch = max_batch;
+  c->pitch = align_up((size_t)max_w, 256);
+  c->plane = c->pitch * (size_t)max_h;
+  for (auto& s : c->slot) {
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&s.k0);
+    if (e == hipSuccess) e = hipEventCreate(&s.k1);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hL, c->plane, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hR, c->plane, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hO, c->plane, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&s.dL, c->plane);
+    if (e == hipSuccess) e = hipMalloc((void**)&s.dR, c->plane);
+    if (e == hipSuccess) e = hipMalloc((void**)&s.dO, c->plane);
+    if (e != hipSuccess) {
+      int st = fail(e == hipErrorOutOfMemory ? SADHIP_ERR_NOMEM : SADHIP_ERR_HIP,
+                    "context buffers (%zu B planes): %s", c->plane, hipGetErrorString(e));
+      destroy_ctx(c);
+      return st;
+    }
+  }
+  *out = c;
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_ctx_destroy(sadhip_ctx* ctx)
+{
+  if (!ctx) return fail(SADHIP_ERR_NULL, "ctx is NULL");
+  destroy_ctx(ctx);
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_ctx_device(const sadhip_ctx* ctx, int* device)
+{
+  if (!ctx || !device) return fail(SADHIP_ERR_NULL, "ctx or device is NULL");
+  *device = ctx->device;
+  return SADHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// validation shared by every disparity entry point
+// ------------------------------------------------------------------------------------------
+static int check_params(int w, int h, int lstride, int rstride, int block, int maxdisp)
+{
+  if (w <= 0 || h <= 0) return fail(SADHIP_ERR_DIMS, "w=%d h=%d", w, h);
+  if (lstride < w || rstride < w) return fail(SADHIP_ERR_STRIDE, "lstride=%d rstride=%d w=%d", lstride, rstride, w);
+  if (block < 1 || block > SADHIP_MAX_BLOCK) return fail(SADHIP_ERR_BLOCK, "block=%d (valid 1..%d)", block, SADHIP_MAX_BLOCK);
+  if (maxdisp < 1 || maxdisp > SADHIP_MAX_MAXDISP)
+    return fail(SADHIP_ERR_MAXDISP, "maxdisp=%d (valid 1..%d; the reference divides by MaxDisparity, sad.go:92)", maxdisp, SADHIP_MAX_MAXDISP);
+  return SADHIP_OK;
+}
+
+static hipError_t dispatch(const Job& j, unsigned flags, hipStream_t s)
+{
+  if (!(flags & SADHIP_FLAG_FORCE_GENERIC) && fast_supported(j)) return launch_fast(j, s);
+  return launch_generic(j, s);
+}
+
+extern "C" int sadhip_kernel_kind(int w, int h, int block, int maxdisp, unsigned flags)
+{
+  if (check_params(w, h, w, w, block, maxdisp) != SADHIP_OK) return -1;
+  Job j{}; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp; j.n = 1;
+  j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.lstride = j.rstride = j.ostride = w;
+  if (flags & SADHIP_FLAG_FORCE_GENERIC) return 0;
+  return fast_supported(j) ? 1 : 0;
+}
+
+// copy rows [r0,r1) of a host image (stride) into compact staging rows (pitch), staging row 0 = r0
+static void stage_rows(uint8_t* dst, size_t pitch, const uint8_t* src, int stride, int w, int r0, int r1)
+{
+  if (r1 <= r0) return;
+  if ((size_t)stride == pitch) {   // contiguous: one copy (last row only w bytes: never read past the image)
+    memcpy(dst, src + (size_t)r0 * stride, (size_t)(r1 - r0 - 1) * pitch + (size_t)w);
+    return;
+  }
+  for (int r = r0; r < r1; ++r) memcpy(dst + (size_t)(r - r0) * pitch, src + (size_t)r * stride, (size_t)w);
+}
+
+using clk = std::chrono::steady_clock;
+
+// One frame (or band of a frame) through slot s: stage -> H2D -> kernel -> D2H, all async on
+// the slot's stream.  rows [band0,band1) of the inputs are uploaded.
+static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint8_t* right,
+                         int w, int h, int lstride, int rstride, int block, int maxdisp, unsigned flags,
+                         int x0, int y0, int x1, int y1, int band0, int band1)
+{
+  const size_t pitch = c->pitch;
+  stage_rows(s.hL, pitch, left, lstride, w, band0, band1);
+  stage_rows(s.hR, pitch, right, rstride, w, band0, band1);
+  const size_t bytes = (size_t)(band1 - band0) * pitch;
+  HIPTRY(hipMemcpyAsync(s.dL, s.hL, bytes, hipMemcpyHostToDevice, s.stream));
+  HIPTRY(hipMemcpyAsync(s.dR, s.hR, bytes, hipMemcpyHostToDevice, s.stream));
+  Job j{};
+  j.left = s.dL; j.right = s.dR; j.out = s.dO;
+  j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = c->plane;
+  j.lstride = j.rstride = j.ostride = (int)pitch;
+  j.n = 1; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
+  j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1;
+  j.ox = 0; j.oy = y0;            // staging output: row 0 = image row y0, full-width rows
+  j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0;
+  j.row0 = band0;
+  HIPTRY(hipEventRecord(s.k0, s.stream));
+  HIPTRY(dispatch(j, flags, s.stream));
+  HIPTRY(hipEventRecord(s.k1, s.stream));
+  HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)(y1 - y0) * pitch, hipMemcpyDeviceToHost, s.stream));
+  return SADHIP_OK;
+}
+
+static int finish_frame(sadhip_ctx* c, Slot& s, int x0, int y0, int x1, int y1, uint8_t* out, int ostride,
+                        float* kernel_ms)
+{
+  HIPTRY(hipStreamSynchronize(s.stream));
+  float ms = 0.f;
+  HIPTRY(hipEventElapsedTime(&ms, s.k0, s.k1));
+  if (kernel_ms) *kernel_ms += ms;
+  const int rw = x1 - x0;
+  for (int r = 0; r < y1 - y0; ++r)
+    memcpy(out + (size_t)r * ostride, s.hO + (size_t)r * c->pitch + x0, (size_t)rw);
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_disparity_region_u8(sadhip_ctx* ctx, const uint8_t* left, const uint8_t* right,
+                                          int w, int h, int lstride, int rstride,
+                                          int block, int maxdisp, unsigned flags,
+                                          int x0, int y0, int x1, int y1, uint8_t* out_region)
+{
+  if (!ctx || !left || !right || !out_region) return fail(SADHIP_ERR_NULL, "ctx/left/right/out is NULL");
+  if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+  if (x0 < 0 || y0 < 0 || x1 > w || y1 > h || x0 >= x1 || y0 >= y1)
+    return fail(SADHIP_ERR_REGION, "region (%d,%d)-(%d,%d) not inside %dx%d", x0, y0, x1, y1, w, h);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPTRY(hipSetDevice(ctx->device));
+  const auto t0 = clk::now();
+  const int hs = block / 2;
+  const int band0 = y0 - hs < 0 ? 0 : y0 - hs;
+  const int band1 = y1 + hs > h ? h : y1 + hs;
+  Slot& s = ctx->slot[0];
+  if (int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags,
+                             x0, y0, x1, y1, band0, band1)) return st;
+  float kms = 0.f;
+  if (int st = finish_frame(ctx, s, x0, y0, x1, y1, out_region, x1 - x0, &kms)) return st;
+  ctx->last_kernel_ms = kms;
+  ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_disparity_u8(sadhip_ctx* ctx, const uint8_t* left, const uint8_t* right,
+                                   int w, int h, int lstride, int rstride,
+                                   int block, int maxdisp, unsigned flags, uint8_t* out, int ostride)
+{
+  if (!ctx || !left || !right || !out) return fail(SADHIP_ERR_NULL, "ctx/left/right/out is NULL");
+  if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
+  if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPTRY(hipSetDevice(ctx->device));
+  const auto t0 = clk::now();
+  Slot& s = ctx->slot[0];
+  if (int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags,
+                             0, 0, w, h, 0, h)) return st;
+  float kms = 0.f;
+  if (int st = finish_frame(ctx, s, 0, 0, w, h, out, ostride, &kms)) return st;
+  ctx->last_kernel_ms = kms;
+  ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
+                                         const uint8_t* const* lefts, const uint8_t* const* rights,
+                                         int w, int h, int lstride, int rstride,
+                                         int block, int maxdisp, unsigned flags,
+                                         uint8_t* const* outs, int ostride)
+{
+  if (!ctx) return fail(SADHIP_ERR_NULL, "ctx is NULL");
+  if (n < 0) return fail(SADHIP_ERR_BATCH, "n=%d", n);
+  if (n == 0) return SADHIP_OK;
+  if (!lefts || !rights || !outs) return fail(SADHIP_ERR_NULL, "lefts/rights/outs is NULL");
+  for (int i = 0; i < n; ++i)
+    if (!lefts[i] || !rights[i] || !outs[i]) return fail(SADHIP_ERR_NULL, "frame %d has a NULL pointer", i);
+  if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
+  if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPTRY(hipSetDevice(ctx->device));
+  const auto t0 = clk::now();
+  float kms = 0.f;
+  // two-slot software pipeline: while slot A's frame is on the GPU, the host stages and
+  // enqueues the next frame on slot B, then drains A.
+  constexpr int S = sadhip_ctx::kSlots;
+  for (int i = 0; i < n + S - 1; ++i) {
+    if (i < n) {
+      if (int st = enqueue_frame(ctx, ctx->slot[i % S], lefts[i], rights[i], w, h, lstride, rstride,
+                                 block, maxdisp, flags, 0, 0, w, h, 0, h)) {
+        for (auto& s : ctx->slot) (void)hipStreamSynchronize(s.stream);
+        return st;
+      }
+    }
+    const int d = i - (S - 1);
+    if (d >= 0) {
+      if (int st = finish_frame(ctx, ctx->slot[d % S], 0, 0, w, h, outs[d], ostride, &kms)) {
+        for (auto& s : ctx->slot) (void)hipStreamSynchronize(s.stream);
+        return st;
+      }
+    }
+  }
+  ctx->last_kernel_ms = kms;
+  ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_disparity_dev_u8(sadhip_ctx* ctx, int n,
+                                       const uint8_t* d_left, const uint8_t* d_right,
+                                       size_t left_frame_stride, size_t right_frame_stride,
+                                       int w, int h, int lstride, int rstride,
+                                       int block, int maxdisp, unsigned flags,
+                                       uint8_t* d_out, size_t out_frame_stride, int ostride,
+                                       void* hip_stream)
+{
+  if (!ctx) return fail(SADHIP_ERR_NULL, "ctx is NULL");
+  if (n < 0) return fail(SADHIP_ERR_BATCH, "n=%d", n);
+  if (n == 0) return SADHIP_OK;
+  if (!d_left || !d_right || !d_out) return fail(SADHIP_ERR_NULL, "d_left/d_right/d_out is NULL");
+  if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
+  if (n > 1) {
+    const size_t need_l = (size_t)(h - 1) * lstride + w, need_r = (size_t)(h - 1) * rstride + w,
+                 need_o = (size_t)(h - 1) * ostride + w;
+    if (left_frame_stride < need_l || right_frame_stride < need_r || out_frame_stride < need_o)
+      return fail(SADHIP_ERR_STRIDE, "frame strides (%zu,%zu,%zu) smaller than a frame", left_frame_stride,
+                  right_frame_stride, out_frame_stride);
+  }
+  // no ctx mutex: pure enqueue on the caller's stream, no context buffers touched
+  HIPTRY(hipSetDevice(ctx->device));
+  Job j{};
+  j.left = d_left; j.right = d_right; j.out = d_out;
+  j.left_frame_stride = left_frame_stride; j.right_frame_stride = right_frame_stride;
+  j.out_frame_stride = out_frame_stride;
+  j.lstride = lstride; j.rstride = rstride; j.ostride = ostride;
+  j.n = n; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
+  j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.ox = 0; j.oy = 0;
+  j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->slot[0].stream;
+  HIPTRY(dispatch(j, flags, s));
+  return SADHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// SumAbsoluteDifferences queries
+// ------------------------------------------------------------------------------------------
+extern "C" int sadhip_sad_windows_u8(sadhip_ctx* ctx,
+                                     const uint8_t* left, int lw, int lh, int lstride,
+                                     const uint8_t* right, int rw, int rh, int rstride,
+                                     int block, int n, const int32_t* queries, int32_t* out_sad)
+{
+  if (!ctx || !left || !right) return fail(SADHIP_ERR_NULL, "ctx/left/right is NULL");
+  if (n < 0) return fail(SADHIP_ERR_BATCH, "n=%d", n);
+  if (lw <= 0 || lh <= 0 || rw <= 0 || rh <= 0) return fail(SADHIP_ERR_DIMS, "left %dx%d right %dx%d", lw, lh, rw, rh);
+  if (lstride < lw || rstride < rw) return fail(SADHIP_ERR_STRIDE, "lstride=%d rstride=%d", lstride, rstride);
+  if (block < 1 || block > SADHIP_MAX_BLOCK) return fail(SADHIP_ERR_BLOCK, "block=%d", block);
+  if (n == 0) return SADHIP_OK;
+  if (!queries || !out_sad) return fail(SADHIP_ERR_NULL, "queries/out_sad is NULL");
+  // The reference indexes Pix with unchecked offsets and panics when a window starts outside
+  // the left image (sad.go:228,234); reject such queries instead.
+  for (int i = 0; i < n; ++i) {
+    const int lx = queries[4 * i], ly = queries[4 * i + 1];
+    if (lx < 0 || ly < 0 || lx >= lw || ly >= lh)
+      return fail(SADHIP_ERR_ARG, "query %d: left centre (%d,%d) outside the %dx%d left image", i, lx, ly, lw, lh);
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPTRY(hipSetDevice(ctx->device));
+  const size_t lbytes = (size_t)lw * lh, rbytes = (size_t)rw * rh;
+  const size_t qbytes = (size_t)n * 16, obytes = (size_t)n * 4;
+  const size_t off_r = align_up(lbytes, 256), off_q = off_r + align_up(rbytes, 256), off_o = off_q + align_up(qbytes, 256);
+  const size_t total = off_o + align_up(obytes, 256);
+  if (int st = ensure_scratch(ctx, total, total)) return st;
+  uint8_t* hs = (uint8_t*)ctx->h_scratch; uint8_t* ds = (uint8_t*)ctx->d_scratch;
+  for (int r = 0; r < lh; ++r) memcpy(hs + (size_t)r * lw, left + (size_t)r * lstride, (size_t)lw);
+  for (int r = 0; r < rh; ++r) memcpy(hs + off_r + (size_t)r * rw, right + (size_t)r * rstride, (size_t)rw);
+  memcpy(hs + off_q, queries, qbytes);
+  hipStream_t s = ctx->slot[0].stream;
+  HIPTRY(hipMemcpyAsync(ds, hs, off_o, hipMemcpyHostToDevice, s));
+  HIPTRY(launch_sad_windows(ds, lw, lh, lw, ds + off_r, rw, rh, rw, block, n,
+                            (const int32_t*)(ds + off_q), (int32_t*)(ds + off_o), s));
+  HIPTRY(hipMemcpyAsync(hs + off_o, ds + off_o, obytes, hipMemcpyDeviceToHost, s));
+  HIPTRY(hipStreamSynchronize(s));
+  memcpy(out_sad, hs + off_o, obytes);
+  return SADHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gray conversion and the fused RGBA entry point
+// ------------------------------------------------------------------------------------------
+static int check_pix(const uint8_t* pix, int channels, int w, int h, int stride)
+{
+  if (!pix) return fail(SADHIP_ERR_NULL, "pix is NULL");
+  if (channels != 3 && channels != 4) return fail(SADHIP_ERR_ARG, "channels=%d (3 or 4)", channels);
+  if (w <= 0 || h <= 0) return fail(SADHIP_ERR_DIMS, "w=%d h=%d", w, h);
+  if ((long long)stride < (long long)w * channels) return fail(SADHIP_ERR_STRIDE, "stride=%d < w*channels", stride);
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_gray_u8(sadhip_ctx* ctx, const uint8_t* pix, int channels,
+                              int w, int h, int stride, uint8_t* gray, int gstride)
+{
+  if (!ctx || !gray) return fail(SADHIP_ERR_NULL, "ctx/gray is NULL");
+  if (int st = check_pix(pix, channels, w, h, stride)) return st;
+  if (gstride < w) return fail(SADHIP_ERR_STRIDE, "gstride=%d w=%d", gstride, w);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPTRY(hipSetDevice(ctx->device));
+  const size_t prow = align_up((size_t)w * channels, 16), pbytes = prow * h;
+  const size_t grow = align_up((size_t)w, 16), gbytes = grow * h;
+  const size_t off_g = align_up(pbytes, 256);
+  if (int st = ensure_scratch(ctx, off_g + gbytes, off_g + gbytes)) return st;
+  uint8_t* hs = (uint8_t*)ctx->h_scratch; uint8_t* ds = (uint8_t*)ctx->d_scratch;
+  for (int r = 0; r < h; ++r) memcpy(hs + (size_t)r * prow, pix + (size_t)r * stride, (size_t)w * channels);
+  hipStream_t s = ctx->slot[0].stream;
+  HIPTRY(hipMemcpyAsync(ds, hs, pbytes, hipMemcpyHostToDevice, s));
+  HIPTRY(launch_gray(ds, channels, w, h, (int)prow, ds + off_g, (int)grow, s));
+  HIPTRY(hipMemcpyAsync(hs + off_g, ds + off_g, gbytes, hipMemcpyDeviceToHost, s));
+  HIPTRY(hipStreamSynchronize(s));
+  for (int r = 0; r < h; ++r) memcpy(gray + (size_t)r * gstride, hs + off_g + (size_t)r * grow, (size_t)w);
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
+                                        const uint8_t* left_pix, const uint8_t* right_pix, int channels,
+                                        int w, int h, int lstride, int rstride,
+                                        int block, int maxdisp, unsigned flags,
+                                        uint8_t* out, int ostride)
+{
+  if (!ctx || !out) return fail(SADHIP_ERR_NULL, "ctx/out is NULL");
+  if (int st = check_pix(left_pix, channels, w, h, lstride)) return st;
+  if (int st = check_pix(right_pix, channels, w, h, rstride)) return st;
+  if (int st = check_params(w, h, w, w, block, maxdisp)) return st;
+  if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
+  if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPTRY(hipSetDevice(ctx->device));
+  const auto t0 = clk::now();
+  const size_t prow = align_up((size_t)w * channels, 16), pbytes = align_up(prow * h, 256);
+  if (int st = ensure_scratch(ctx, 2 * pbytes, 2 * pbytes)) return st;
+  uint8_t* hs = (uint8_t*)ctx->h_scratch; uint8_t* ds = (uint8_t*)ctx->d_scratch;
+  for (int r = 0; r < h; ++r) {
+    memcpy(hs + (size_t)r * prow, left_pix + (size_t)r * lstride, (size_t)w * channels);
+    memcpy(hs + pbytes + (size_t)r * prow, right_pix + (size_t)r * rstride, (size_t)w * channels);
+  }
+  Slot& s = ctx->slot[0];
+  HIPTRY(hipMemcpyAsync(ds, hs, 2 * pbytes, hipMemcpyHostToDevice, s.stream));
+  HIPTRY(hipEventRecord(s.k0, s.stream));
+  HIPTRY(launch_gray(ds, channels, w, h, (int)prow, s.dL, (int)ctx->pitch, s.stream));
+  HIPTRY(launch_gray(ds + pbytes, channels, w, h, (int)prow, s.dR, (int)ctx->pitch, s.stream));
+  Job j{};
+  j.left = s.dL; j.right = s.dR; j.out = s.dO;
+  j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = ctx->plane;
+  j.lstride = j.rstride = j.ostride = (int)ctx->pitch;
+  j.n = 1; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
+  j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.ox = 0; j.oy = 0;
+  j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
+  HIPTRY(dispatch(j, flags, s.stream));
+  HIPTRY(hipEventRecord(s.k1, s.stream));
+  HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)h * ctx->pitch, hipMemcpyDeviceToHost, s.stream));
+  float kms = 0.f;
+  if (int st = finish_frame(ctx, s, 0, 0, w, h, out, ostride, &kms)) return st;
+  ctx->last_kernel_ms = kms;
+  ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_last_timing(sadhip_ctx* ctx, float* kernel_ms, float* total_ms)
+{
+  if (!ctx) return fail(SADHIP_ERR_NULL, "ctx is NULL");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (kernel_ms) *kernel_ms = ctx->last_kernel_ms;
+  if (total_ms) *total_ms = ctx->last_total_ms;
+  return SADHIP_OK;
+}

@@ -1,0 +1,48 @@
+// sadhip_kernels.h -- launch interface between the C-ABI host code (sadhip.hip) and the
+// gfx950 kernels (kernels_generic.hip, kernels_fast.hip).  Internal; not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace sadhip {
+
+// One batched disparity job on device-resident frames.  Frame f of each plane lives at
+// base + f * frame_stride bytes; rows are `stride` bytes apart.  The output rectangle is
+// [x0,x1) x [y0,y1) of every frame, written at out + f*out_frame_stride + (y-oy)*ostride + (x-ox)
+// (ox,oy = origin of the output buffer in image coordinates: (0,0) for whole frames,
+// (x0,y0) for region-local output).
+struct Job {
+  const uint8_t* left;  size_t left_frame_stride;  int lstride;
+  const uint8_t* right; size_t right_frame_stride; int rstride;
+  uint8_t* out;         size_t out_frame_stride;   int ostride;
+  int n;                 // frames
+  int w, h;              // image size
+  int block, maxdisp;    // BlockSize, MaxDisparity (pkg/despair/params.go:32-37)
+  int x0, y0, x1, y1;    // output rectangle (image coordinates)
+  int ox, oy;            // output buffer origin (image coordinates)
+  int raw;               // 1: store best d (clamped to 255); 0: best*255/maxdisp
+  // Rows of the input planes actually present in memory: plane row r holds image row r + row0
+  // (row0 = 0 for whole frames; > 0 when only a band was uploaded for a region call).
+  int row0;
+};
+
+// Generic kernel: any block / maxdisp / size.  One thread per output pixel, closed-form
+// restatement of sad.go:55-94 with u32 accumulators.  Always available.
+hipError_t launch_generic(const Job& j, hipStream_t s);
+
+// Fast kernel (kernels_fast.hip): returns true if it supports the job's parameters.
+bool fast_supported(const Job& j);
+hipError_t launch_fast(const Job& j, hipStream_t s);
+
+// Single-window SADs, literal clamps of sad.go:205-244.
+hipError_t launch_sad_windows(const uint8_t* left, int lw, int lh, int lstride,
+                              const uint8_t* right, int rw, int rh, int rstride,
+                              int block, int n, const int32_t* queries, int32_t* out,
+                              hipStream_t s);
+
+// Gray conversion (gray.go:43-58 on NRGBA / opaque RGB), n planes.
+hipError_t launch_gray(const uint8_t* pix, int channels, int w, int h, int stride,
+                       uint8_t* gray, int gstride, hipStream_t s);
+
+}  // namespace sadhip

@@ -1,0 +1,170 @@
+"""Python mirror of the Go API surface of pkg/despair, running on the HIP library.
+
+Same names, argument meaning and ownership rules as the reference
+(pkg/despair/sad.go, params.go); used by tests and examples so they read like reference
+callers (examples/run.go, examples/run.stream.go, pkg/camera/output.go).  The C++ mirror and
+the cgo shim (host/) are the artefacts a Go maintainer consumes; this module is their ctypes
+twin.  Images are 2-D uint8 numpy arrays (image.Gray with Rect.Min == (0,0)); a rectangle is
+(x0, y0, x1, y1) like image.Rect.
+
+Differences from the reference, all deliberate:
+  * AssembleDisparityMap writes every chunk it receives (the reference drops the last one,
+    sad.go:181-184);
+  * MaxDisparity < 1 raises instead of panicking with a divide by zero (sad.go:92);
+  * there is no CPU path here: without the HIP library / a GPU every call raises.
+"""
+import queue
+import threading
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class Parameters:
+    """params.go:32-37"""
+    BlockSize: int = 16
+    MaxDisparity: int = 64
+
+
+_default_params = Parameters(BlockSize=16, MaxDisparity=64)   # params.go:13-18
+_default_params_mu = threading.Lock()
+
+
+def SetDefaultParams(params):
+    """params.go:21-25"""
+    global _default_params
+    with _default_params_mu:
+        _default_params = Parameters(params.BlockSize, params.MaxDisparity)
+
+
+def DefaultParams():
+    """params.go:28-30"""
+    return _default_params
+
+
+@dataclass
+class InputChunk:
+    """sad.go:11-15"""
+    Left: np.ndarray
+    Right: np.ndarray
+    Region: tuple
+
+
+@dataclass
+class OutputChunk:
+    """sad.go:17-21"""
+    DisparityData: np.ndarray   # flat uint8, row-major within Region
+    Region: tuple
+
+
+_CLOSED = object()
+
+
+class Chan:
+    """Minimal Go-channel stand-in: send / iterate / close."""
+
+    def __init__(self, cap):
+        self._q = queue.Queue(maxsize=cap)
+
+    def send(self, v):
+        self._q.put(v)
+
+    def close(self):
+        self._q.put(_CLOSED)
+
+    def __iter__(self):
+        while True:
+            v = self._q.get()
+            if v is _CLOSED:
+                self._q.put(_CLOSED)   # let other consumers see the close too
+                return
+            yield v
+
+
+_ctx_lock = threading.Lock()
+_ctx = None
+_ctx_cap = (0, 0)
+
+
+def _context(w, h, device=0):
+    """Process-wide device context, grown on demand (the worker pool of sad.go:41-104)."""
+    global _ctx, _ctx_cap
+    with _ctx_lock:
+        if _ctx is None or w > _ctx_cap[0] or h > _ctx_cap[1]:
+            if _ctx is not None:
+                _ctx.close()
+            _ctx_cap = (max(w, _ctx_cap[0], 1920), max(h, _ctx_cap[1], 1080))
+            _ctx = capi.Context(device, _ctx_cap[0], _ctx_cap[1], 1)
+        return _ctx
+
+
+def SetupConcurrentSAD(numWorkers):
+    """sad.go:29-113.  Returns (inputChan, outputChan).  One device worker replaces the
+    goroutine pool; parameters are snapshotted per chunk (sad.go:51-53); closing the input
+    channel stops the worker, which then closes the output channel (sad.go:106-110)."""
+    if numWorkers <= 0:
+        numWorkers = 32
+    inp, outp = Chan(numWorkers * 2), Chan(numWorkers * 2)
+
+    def worker():
+        try:
+            for chunk in inp:
+                with _default_params_mu:
+                    p = Parameters(_default_params.BlockSize, _default_params.MaxDisparity)
+                h, w = chunk.Left.shape
+                data = _context(w, h).disparity_region(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity,
+                                                       chunk.Region)
+                outp.send(OutputChunk(DisparityData=data.reshape(-1), Region=chunk.Region))
+        finally:
+            outp.close()
+
+    threading.Thread(target=worker, daemon=True).start()
+    return inp, outp
+
+
+def AssembleDisparityMap(outputChan, dimensions, chunks):
+    """sad.go:172-202, without the dropped-chunk bug: all ``chunks`` chunks are written."""
+    x0, y0, x1, y1 = dimensions
+    disparityMap = np.zeros((y1 - y0, x1 - x0), np.uint8)
+    i = 0
+    for chunk in outputChan:
+        cx0, cy0, cx1, cy1 = chunk.Region
+        disparityMap[cy0 - y0:cy1 - y0, cx0 - x0:cx1 - x0] = chunk.DisparityData.reshape(cy1 - cy0, cx1 - cx0)
+        i += 1
+        if i >= chunks:
+            break
+    return disparityMap
+
+
+def RunSad(left, right, blockSize, maxDisparity):
+    """sad.go:119-169: sets the global parameters (:123-126) and returns the full map.
+    One frame-level device call replaces tiling + channel assembly (values do not depend on
+    the tiling: every worker reads the full shared images, sad.go:69-77)."""
+    SetDefaultParams(Parameters(BlockSize=blockSize, MaxDisparity=maxDisparity))
+    h, w = left.shape
+    return _context(w, h).disparity(left, right, blockSize, maxDisparity)
+
+
+def SumAbsoluteDifferences(left, right, leftX, leftY, rightX, rightY, blockSize):
+    """sad.go:205-244 (one query through the batched device entry point)."""
+    h, w = left.shape
+    return int(_context(w, h).sad_windows(left, right, blockSize, [(leftX, leftY, rightX, rightY)])[0])
+
+
+def run_sad_tiles(w, h, num_cpu):
+    """The tile rectangles RunSad feeds (sad.go:128-153), for callers that mirror its chunking."""
+    import math
+    numChunks = num_cpu * 4 * 4
+    chunkWidth = int(math.sqrt((w * h) // numChunks))
+    horChunks = max(1, w // chunkWidth) if chunkWidth > 0 else 1
+    verChunks = max(1, numChunks // horChunks)
+    chunkWidth = w // horChunks
+    chunkHeight = h // verChunks
+    rects = []
+    for sy in range(0, h, max(chunkHeight, 1)):
+        for sx in range(0, w, max(chunkWidth, 1)):
+            rects.append((sx, sy, min(sx + chunkWidth, w), min(sy + chunkHeight, h)))
+    return rects

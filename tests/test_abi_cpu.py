@@ -1,0 +1,93 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/sadhip.h declares, validates arguments without touching a GPU, and fails loudly
+(never falls back) when no device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import steroscopic_hardware_amd as sha
+from steroscopic_hardware_amd import capi
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        return capi.device_count() > 0
+    except capi.SadHipError:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "sadhip.h")).read()
+    declared = set(re.findall(r"SADHIP_API\s+[\w\s\*]+?\b(sadhip_\w+)\s*\(", hdr))
+    assert len(declared) >= 16
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+    l = C.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(l, name), f"{name} not exported"
+    assert capi.lib().sadhip_abi_version() == 1
+
+
+def test_status_strings():
+    l = capi.lib()
+    assert l.sadhip_status_string(0) == b"ok"
+    for s in range(1, 12):
+        assert l.sadhip_status_string(s) not in (b"ok", b"unknown status")
+    assert l.sadhip_status_string(99) == b"unknown status"
+
+
+def test_kernel_kind_validates():
+    assert capi.kernel_kind(1920, 1080, 9, 64) in (0, 1)
+    assert capi.kernel_kind(1920, 1080, 9, 64, capi.FLAG_FORCE_GENERIC) == 0
+    assert capi.kernel_kind(1920, 1080, 9, 0) == -1          # MaxDisparity 0: reference divides by zero
+    assert capi.kernel_kind(0, 10, 9, 64) == -1
+    assert capi.kernel_kind(10, 10, 0, 64) == -1
+
+
+def test_null_and_bad_args_are_status_codes_not_crashes():
+    l = capi.lib()
+    assert l.sadhip_device_count(None) == capi.ERR_NULL
+    assert l.sadhip_ctx_create(0, 64, 64, 1, None) == capi.ERR_NULL
+    h = C.c_void_p()
+    assert l.sadhip_ctx_create(0, 0, 64, 1, C.byref(h)) == capi.ERR_DIMS
+    assert l.sadhip_ctx_create(0, 64, 64, 0, C.byref(h)) == capi.ERR_BATCH
+    assert l.sadhip_ctx_destroy(None) == capi.ERR_NULL
+    assert l.sadhip_disparity_u8(None, None, None, 8, 8, 8, 8, 7, 32, 0, None, 8) == capi.ERR_NULL
+    assert b"NULL" in l.sadhip_last_error()
+
+
+@pytest.mark.skipif(_has_gpu(), reason="this container-side test asserts the no-GPU behaviour")
+def test_no_gpu_fails_loudly_no_cpu_fallback():
+    with pytest.raises(capi.SadHipError) as ei:
+        capi.Context(0, 64, 64, 1)
+    assert ei.value.status in (capi.ERR_NO_DEVICE, capi.ERR_HIP)
+    L = np.zeros((8, 8), np.uint8)
+    with pytest.raises(capi.SadHipError):
+        sha.despair.RunSad(L, L, 7, 32)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(REPO, "steroscopic-hardware_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".go", "Makefile")):
+                txt = open(os.path.join(root, f), errors="replace").read()
+                assert "despair_oracle" not in txt and "import oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_despair_param_plumbing_and_tiles():
+    d = sha.despair
+    d.SetDefaultParams(d.Parameters(BlockSize=9, MaxDisparity=48))
+    assert (d.DefaultParams().BlockSize, d.DefaultParams().MaxDisparity) == (9, 48)
+    d.SetDefaultParams(d.Parameters(BlockSize=16, MaxDisparity=64))
+    # sad.go:128-153 with 8 CPUs on 640x480: 14 x 10 near-square tiles of 45x48 (+ remainders)
+    rects = d.run_sad_tiles(640, 480, 8)
+    cover = np.zeros((480, 640), np.int32)
+    for x0, y0, x1, y1 in rects:
+        cover[y0:y1, x0:x1] += 1
+    assert (cover == 1).all()

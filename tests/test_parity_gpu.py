@@ -1,0 +1,282 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the committed
+golden fixtures, and -- at BASELINE sizes -- size-independent properties.  Bit-exact (u8 / int).
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import steroscopic_hardware_amd as sha
+from steroscopic_hardware_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+BOTH = [0, capi.FLAG_FORCE_GENERIC]          # dispatcher's choice, and the generic kernel
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert os.path.exists(capi.LIB_PATH), "libsadhip.so must be built in-tree (no fallback)"
+    c = capi.Context(0, 3840, 2160, 1)
+    yield c
+    c.close()
+
+
+def _expect(L, R, block, maxdisp, raw=False):
+    return oracle.disparity_closed(L, R, block, maxdisp, raw=raw)
+
+
+# ---- config 2: 640x480 synthetic, block 7, D 32 (bit-exact vs despair) ----------------------
+@pytest.mark.parametrize("flags", BOTH)
+def test_config2_640x480_b7_d32(ctx, flags):
+    L, R = sha.synth.synth_pair(2, 640, 480)
+    exp = oracle.disparity_literal(L, R, 7, 32)          # the literal restatement of sad.go:55-94
+    got = ctx.disparity(L, R, 7, 32, flags)
+    assert np.array_equal(got, exp)
+
+
+# ---- config 1: the reference's real pair through the Go gray formula --------------------------
+@pytest.mark.parametrize("flags", BOTH)
+def test_config1_real_pair(ctx, testdata_pair, flags):
+    L, R = testdata_pair
+    got = ctx.disparity(L, R, 7, 32, flags)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == "03a658082e809b4211a1216839d23a7123f1187b56f18dff0b21b6863c8a9d6e"
+    assert np.array_equal(got, oracle.disparity_literal(L, R, 7, 32))
+    got2 = ctx.disparity(L, R, 9, 64, flags)
+    assert hashlib.sha256(got2.tobytes()).hexdigest() == "0bde916590100d42d2fb6c0aca7081ba4f912c2b03a8f3bb5a8d9946454317fb"
+
+
+def test_real_pair_default_params_16_64(ctx, testdata_pair):
+    """examples/run.go:30 calls RunSad(..., 16, 64): even BlockSize -> 17x17 window."""
+    L, R = testdata_pair
+    assert np.array_equal(sha.despair.RunSad(L, R, 16, 64), _expect(L, R, 16, 64))
+    assert (sha.despair.DefaultParams().BlockSize, sha.despair.DefaultParams().MaxDisparity) == (16, 64)
+
+
+# ---- hardware fixtures through the GPU (raw d) -------------------------------------------------
+@pytest.mark.parametrize("flags", BOTH)
+def test_hardware_fixture_regions(ctx, hwfx, flags):
+    hs, D = 7, 64
+    for k in range(4):
+        got = ctx.disparity(hwfx["patch_L"][k], hwfx["patch_R"][k], 15, 64, flags | capi.FLAG_RAW)
+        assert np.array_equal(got[:, D + hs:128 - hs], hwfx["exp_disp_p"][k][:, D + hs:128 - hs])
+    got = ctx.disparity(hwfx["patch_L"][1], hwfx["patch_R"][1], 15, 64, flags | capi.FLAG_RAW)
+    assert np.array_equal(got[hs:128 - hs, D + hs:128 - hs], hwfx["exp_disp_sadc"][hs:128 - hs, D + hs:128 - hs])
+
+
+# ---- adversarial / edge shapes ------------------------
+EDGE = [  # (w, h, block, maxdisp)
+    (1, 1, 7, 32), (5, 4, 15, 16), (40, 33, 9, 64), (33, 20, 16, 64), (50, 40, 31, 256),
+    (97, 31, 3, 16), (70, 25, 5, 48), (128, 20, 15, 64), (30, 30, 1, 8), (45, 17, 2, 5),
+    (257, 37, 9, 64), (300, 70, 7, 32), (513, 9, 11, 96), (64, 200, 13, 16), (1000, 12, 9, 128),
+    (130, 66, 9, 1), (90, 50, 21, 40),
+]
+
+
+@pytest.mark.parametrize("flags", BOTH)
+@pytest.mark.parametrize("w,h,block,maxdisp", EDGE)
+def test_edge_shapes(ctx, w, h, block, maxdisp, flags):
+    L, R = sha.synth.synth_pair(100 + w + h, w, h)
+    assert np.array_equal(ctx.disparity(L, R, block, maxdisp, flags), _expect(L, R, block, maxdisp))
+    assert np.array_equal(ctx.disparity(L, R, block, maxdisp, flags | capi.FLAG_RAW),
+                          np.minimum(_expect(L, R, block, maxdisp, raw=True), 255))
+
+
+@pytest.mark.parametrize("flags", BOTH)
+def test_flat_images_tie_to_zero(ctx, flags):
+    L = np.full((90, 300), 200, np.uint8)
+    assert not ctx.disparity(L, L.copy(), 9, 64, flags).any()
+    # ties between distinct d: periodic texture -> lowest d must win (strict '<', sad.go:79)
+    x = np.arange(300)
+    P = np.tile(((x % 8) * 30).astype(np.uint8), (60, 1))
+    got = ctx.disparity(P, P.copy(), 9, 64, flags | capi.FLAG_RAW)
+    assert np.array_equal(got, _expect(P, P.copy(), 9, 64, raw=True))
+    assert not got.any()
+
+
+@pytest.mark.parametrize("flags", BOTH)
+def test_strided_inputs_and_output(ctx, flags):
+    big_l, big_r = sha.synth.synth_pair(77, 400, 120)
+    L, R = big_l[10:100, 37:337], big_r[10:100, 37:337]          # non-contiguous views, odd base alignment
+    out = np.full((90, 333), 0xAB, np.uint8)
+    ctx.disparity(L, R, 9, 64, flags, out=out[:, 5:305])
+    exp = _expect(np.ascontiguousarray(L), np.ascontiguousarray(R), 9, 64)
+    assert np.array_equal(out[:, 5:305], exp)
+    assert (out[:, :5] == 0xAB).all() and (out[:, 305:] == 0xAB).all()     # nothing written outside
+
+
+@pytest.mark.parametrize("flags", BOTH)
+def test_regions_like_the_callers(ctx, flags):
+    """InputChunk.Region semantics: OutputCamera row bands (output.go:172-187) and RunSad tiles
+    (sad.go:138-153); output is region-local row-major (sad.go:48-50,91)."""
+    L, R = sha.synth.synth_pair(9, 320, 131)
+    full = _expect(L, R, 9, 64)
+    chunk = max(1, 131 // (32 * 4))
+    for y in (0, 1, 64, 129, 130):
+        reg = (0, y, 320, min(y + chunk, 131))
+        assert np.array_equal(ctx.disparity_region(L, R, 9, 64, reg, flags), full[reg[1]:reg[3], reg[0]:reg[2]])
+    for reg in sha.despair.run_sad_tiles(320, 131, 8)[::7] + [(311, 120, 320, 131), (0, 0, 1, 1), (100, 50, 101, 51)]:
+        assert np.array_equal(ctx.disparity_region(L, R, 9, 64, reg, flags), full[reg[1]:reg[3], reg[0]:reg[2]])
+
+
+def test_channel_api_round_trip(ctx):
+    """examples/run.stream.go:30-59 shape: long-lived pipeline, row-band chunks, assemble."""
+    d = sha.despair
+    L, R = sha.synth.synth_pair(21, 200, 97)
+    d.SetDefaultParams(d.Parameters(BlockSize=7, MaxDisparity=32))
+    inp, outp = d.SetupConcurrentSAD(32)
+    for _ in range(2):
+        chunkSize = max(1, 97 // (32 * 4))
+        n = 0
+        for y in range(0, 97, chunkSize):
+            inp.send(d.InputChunk(L, R, (0, y, 200, min(y + chunkSize, 97))))
+            n += 1
+        got = d.AssembleDisparityMap(outp, (0, 0, 200, 97), n)
+        assert np.array_equal(got, _expect(L, R, 7, 32))       # hole-free, unlike sad.go:181-184
+    inp.close()
+    assert list(outp) == []
+    d.SetDefaultParams(d.Parameters(BlockSize=16, MaxDisparity=64))
+
+
+def test_batch_host_pipeline(ctx):
+    pairs = [sha.synth.synth_pair(1000 + i, 256, 64) for i in range(5)]
+    outs = ctx.disparity_batch([p[0] for p in pairs], [p[1] for p in pairs], 9, 64)
+    for (L, R), o in zip(pairs, outs):
+        assert np.array_equal(o, _expect(L, R, 9, 64))
+    assert ctx.disparity_batch([], [], 9, 64) == []
+    k_ms, t_ms = ctx.last_timing()
+    assert k_ms > 0 and t_ms >= 0
+
+
+def test_device_resident_batch(ctx):
+    import torch
+    Ls, Rs = sha.synth.synth_batch_torch([1000, 1001, 1002], 300, 80, "cuda:0")
+    out = torch.full_like(Ls, 0xCD)
+    ctx.disparity_dev(Ls, Rs, out, 9, 64)
+    torch.cuda.synchronize()
+    for i in range(3):
+        L, R = sha.synth.synth_pair(1000 + i, 300, 80)
+        assert np.array_equal(Ls[i].cpu().numpy(), L) and np.array_equal(Rs[i].cpu().numpy(), R)
+        assert np.array_equal(out[i].cpu().numpy(), _expect(L, R, 9, 64))
+
+
+# ---- SumAbsoluteDifferences (sad.go:205-244), incl. the independent right clamp ----------------
+def test_sad_windows_kats_and_clamps(ctx, hwfx):
+    wl = np.ascontiguousarray(hwfx["winL"].reshape(15, 15)); wr = np.ascontiguousarray(hwfx["winR"].reshape(15, 15))
+    assert int(ctx.sad_windows(wl, wr, 15, [(7, 7, 7, 7)])[0]) == 18116
+    for k in range(4):
+        L, R = np.ascontiguousarray(hwfx["strips_old_L"][k]), np.ascontiguousarray(hwfx["strips_old_R"][k])
+        assert int(ctx.sad_windows(L, R, 15, [(7, 7, 7, 7)])[0]) == int(hwfx["exp_sad_old"][k])
+    L, R = sha.synth.synth_pair(5, 60, 40)
+    Rs = np.ascontiguousarray(R[:33, :47])                    # smaller right image: early breaks
+    rng = np.random.default_rng(1)
+    q = np.stack([rng.integers(0, 60, 400), rng.integers(0, 40, 400),
+                  rng.integers(-20, 70, 400), rng.integers(-10, 50, 400)], axis=1).astype(np.int32)
+    for block in (1, 7, 16, 31):
+        got = ctx.sad_windows(L, Rs, block, q)
+        exp = [oracle.sum_absolute_differences(L, Rs, *map(int, r), block) for r in q]
+        assert got.tolist() == exp
+    assert sha.despair.SumAbsoluteDifferences(L, R, 30, 20, 25, 20, 9) == oracle.sum_absolute_differences(L, R, 30, 20, 25, 20, 9)
+
+
+# ---- gray conversion (gray.go:43-58 / output.go:142-162) ----------------------------------------
+def test_gray_and_fused_rgba(ctx, testdata_rgba, testdata_pair):
+    la, ra = testdata_rgba
+    assert np.array_equal(ctx.gray(la), testdata_pair[0])
+    assert np.array_equal(ctx.gray(ra), testdata_pair[1])
+    rng = np.random.default_rng(3)
+    for shape in ((7, 13, 4), (33, 65, 3), (1, 1, 4), (20, 1027, 4)):
+        pix = rng.integers(0, 256, shape, dtype=np.uint8)
+        exp = oracle.gray_from_nrgba(pix) if shape[2] == 4 else oracle.gray_from_rgb8(pix)
+        assert np.array_equal(ctx.gray(pix), exp)
+    got = ctx.disparity_rgba(la, ra, 7, 32)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == "03a658082e809b4211a1216839d23a7123f1187b56f18dff0b21b6863c8a9d6e"
+
+
+# ---- error behaviour at the boundary ------------------------------------------------------------
+def test_error_codes(ctx):
+    L = np.zeros((16, 16), np.uint8)
+    for kw, status in (((L, L, 7, 0), capi.ERR_MAXDISP), ((L, L, 0, 32), capi.ERR_BLOCK),
+                       ((L, L, 256, 32), capi.ERR_BLOCK), ((L, L, 7, 5000), capi.ERR_MAXDISP)):
+        with pytest.raises(capi.SadHipError) as ei:
+            ctx.disparity(*kw)
+        assert ei.value.status == status
+    with pytest.raises(capi.SadHipError) as ei:
+        ctx.disparity_region(L, L, 7, 32, (0, 0, 17, 4))
+    assert ei.value.status == capi.ERR_REGION
+    with pytest.raises(capi.SadHipError) as ei:
+        ctx.disparity_region(L, L, 7, 32, (4, 4, 4, 8))
+    assert ei.value.status == capi.ERR_REGION
+    small = capi.Context(0, 32, 32, 1)
+    with pytest.raises(capi.SadHipError) as ei:
+        small.disparity(np.zeros((40, 40), np.uint8), np.zeros((40, 40), np.uint8), 7, 32)
+    assert ei.value.status == capi.ERR_DIMS
+    small.close()
+    with pytest.raises(capi.SadHipError) as ei:
+        capi.Context(99, 32, 32, 1)
+    assert ei.value.status == capi.ERR_NO_DEVICE
+
+
+# ---- BASELINE full sizes: oracle on a sample + size-independent properties ----------------------
+def _props(ctx, L, R, block, maxdisp, flags=0):
+    h, w = L.shape
+    hs = block // 2
+    got = ctx.disparity(L, R, block, maxdisp, flags | capi.FLAG_RAW)
+    sc = ctx.disparity(L, R, block, maxdisp, flags)
+    assert np.array_equal(sc, (got.astype(np.int32) * 255 // maxdisp).astype(np.uint8))       # scaling law
+    assert not got[:, :hs + 1].any()                                                          # x <= hs -> 0
+    xs = np.arange(w)
+    assert (got <= np.minimum(maxdisp, np.maximum(0, xs - hs))[None, :]).all()                # candidate range
+    assert np.array_equal(got, ctx.disparity(L, R, block, maxdisp, flags | capi.FLAG_RAW))    # deterministic
+    # tiling invariance: a band computed alone equals the same rows of the frame (halo-free chunks, sad.go:69-77)
+    y0 = h // 3
+    assert np.array_equal(ctx.disparity_region(L, R, block, maxdisp, (0, y0, w, y0 + 5), flags | capi.FLAG_RAW), got[y0:y0 + 5])
+    # planted shift: the generator's true disparity wins wherever the window is full and un-perturbed enough
+    s = 3 + (xs[None, :] * 7) // w + (np.arange(h)[:, None] * 5) // h
+    inner = (slice(hs, h - hs), slice(maxdisp + hs, w - 16 - hs))
+    assert (got[inner] == s[inner]).mean() > 0.8
+    return got
+
+
+def test_config3_1080p_b9_d64(ctx):
+    L, R = sha.synth.synth_pair(3, 1920, 1080)
+    got = _props(ctx, L, R, 9, 64)
+    for (x0, y0, x1, y1) in ((0, 0, 1920, 6), (0, 1074, 1920, 1080), (0, 500, 120, 540), (1800, 300, 1920, 340), (900, 536, 1100, 546)):
+        assert np.array_equal(got[y0:y1, x0:x1], oracle.disparity_closed(L, R, 9, 64, region=(x0, y0, x1, y1), raw=True))
+    assert np.array_equal(got, ctx.disparity(L, R, 9, 64, capi.FLAG_FORCE_GENERIC | capi.FLAG_RAW))   # two independent kernels agree
+
+
+def test_config5_4k_b15_d128(ctx):
+    L, R = sha.synth.synth_pair(5, 3840, 2160)
+    got = _props(ctx, L, R, 15, 128)
+    for (x0, y0, x1, y1) in ((0, 0, 3840, 2), (0, 2158, 3840, 2160), (0, 1000, 200, 1012), (3700, 77, 3840, 89), (1900, 1075, 2000, 1085)):
+        assert np.array_equal(got[y0:y1, x0:x1], oracle.disparity_closed(L, R, 15, 128, region=(x0, y0, x1, y1), raw=True))
+    band = (0, 700, 3840, 724)
+    assert np.array_equal(got[700:724], ctx.disparity_region(L, R, 15, 128, band, capi.FLAG_FORCE_GENERIC | capi.FLAG_RAW))
+
+
+def test_config4_stream_shard(ctx):
+    """A shard of the 1024-frame stream (frames i = rank, rank+G, ...): device-resident batch,
+    every frame checked against a band of the oracle + a checksum of checksums across two runs."""
+    import torch
+    seeds = [1000 + i for i in (0, 8, 16, 1016)]
+    Ls, Rs = sha.synth.synth_batch_torch(seeds, 1920, 1080, "cuda:0")
+    out = torch.empty_like(Ls)
+    ctx.disparity_dev(Ls, Rs, out, 9, 64)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    d1 = hashlib.sha256(b"".join(hashlib.sha256(o[i].tobytes()).digest() for i in range(len(seeds)))).hexdigest()
+    for i, sd in enumerate(seeds):
+        L, R = sha.synth.synth_pair(sd, 1920, 1080)
+        assert np.array_equal(o[i, 300:304], oracle.disparity_closed(L, R, 9, 64, region=(0, 300, 1920, 304)))
+        assert np.array_equal(o[i], ctx.disparity(L, R, 9, 64))          # batch == single-frame host path
+    out.zero_()
+    ctx.disparity_dev(Ls, Rs, out, 9, 64)
+    torch.cuda.synchronize()
+    o2 = out.cpu().numpy()
+    d2 = hashlib.sha256(b"".join(hashlib.sha256(o2[i].tobytes()).digest() for i in range(len(seeds)))).hexdigest()
+    assert d1 == d2
