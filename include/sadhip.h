@@ -116,7 +116,8 @@ SADHIP_API int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
  * Same function for callers that already hold frames in HBM (bench.py, a capture pipeline
  * that DMA's frames to the GPU).  d_left/d_right/d_out are device pointers on the context's
  * device; n frames, frame f at base + f*frame_stride bytes.  hip_stream is a hipStream_t
- * (NULL = the context's own stream).  Returns after enqueueing; no host synchronisation. */
+ * (NULL = HIP's null stream, which is also PyTorch's default stream).  Returns after enqueueing;
+ * no host synchronisation. */
 SADHIP_API int sadhip_disparity_dev_u8(sadhip_ctx* ctx, int n,
                             const uint8_t* d_left, const uint8_t* d_right,
                             size_t left_frame_stride, size_t right_frame_stride,

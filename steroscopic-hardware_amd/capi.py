@@ -73,6 +73,33 @@ def build_library(force=False):
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """libsadhip.so is linked without a DT_NEEDED on the HIP runtime (csrc/Makefile): make ONE
+    libamdhip64 global before loading it.  Inside a PyTorch process that must be the copy torch
+    bundles (torch/lib/libamdhip64.so); otherwise the system ROCm's.  SADHIP_HIP_RUNTIME overrides."""
+    cands = []
+    if os.environ.get("SADHIP_HIP_RUNTIME"):
+        cands.append(os.environ["SADHIP_HIP_RUNTIME"])
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            import torch  # noqa: F401  (loads its bundled runtime first, with torch's own rpath)
+            cands.append(os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    errs = []
+    for c in cands:
+        if os.path.sep in c and not os.path.exists(c):
+            continue
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            errs.append(f"{c}: {e}")
+    raise ImportError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errs))
+
+
 def lib():
     """Loads libsadhip.so; raises (never falls back) when it is absent or lacks a symbol."""
     global _LIB
@@ -80,6 +107,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+        _preload_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)          # AttributeError if the ABI symbol is not exported
@@ -158,7 +186,7 @@ class Context:
         out = np.empty((max(y1 - y0, 0), max(x1 - x0, 0)), np.uint8)
         _check(lib().sadhip_disparity_region_u8(self._h, left.ctypes.data, right.ctypes.data, w, h,
                                                 left.strides[0], right.strides[0], block, maxdisp, flags,
-                                                x0, y0, x1, y1, out.ctypes.data if out.size else None))
+                                                x0, y0, x1, y1, out.ctypes.data if out.size else np.empty(1, np.uint8).ctypes.data))
         return out
 
     def disparity_batch(self, lefts, rights, block, maxdisp, flags=0):

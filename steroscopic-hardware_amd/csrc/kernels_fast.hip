@@ -1,6 +1,359 @@
-// kernels_fast.hip -- placeholder until the column-wave kernel lands (next commit).
+// kernels_fast.hip -- "column-wave" SAD disparity kernel for gfx950 (MI355X).
+//
+// Function computed (bit-exact with pkg/despair/sad.go:55-94 + :205-244, closed form of
+// SURVEY.md section 8 a-1):   out(x,y) = scale(argmin_{d in [0,min(D,max(0,x-h))]} SAD(x,y,d)),
+// first minimum wins, windows clipped to the image.
+//
+// Mapping (why it looks like this -- measured on MI355X, tools/ubench/valu_rates.hip):
+//   * the path is integer-VALU bound: v_sad_*/min3/DPP ops cost ~4.2 SIMD-cycles per
+//     wave-instruction, plain v_add/v_sub ~2.3, v_qsad_pk_u16_u8 is quarter rate; one LDS dword
+//     per lane costs as much as two such VALU ops.  So: every |L-R| is one v_sad_u32 with the
+//     accumulate folded in, everything else is adds/subs, and operands stay in registers.
+//   * lane l of a wave owns P adjacent columns; a wave owns ND consecutive disparities for its
+//     64*P columns; the NW waves of a workgroup split the disparity range of one tile.
+//   * vertical: each lane keeps the column sums C[p][j] of its (column, disparity) pairs in
+//     registers and slides them down the strip: + |L-R| of the row entering the window (v_sad_u32
+//     with accumulator), - |L-R| of the row leaving it (v_sad_u32 + v_sub).
+//   * horizontal: the (2h+1)-wide window sum of C is formed from in-lane prefix sums plus 2h
+//     values fetched from the two neighbour lanes with DPP wave_shr:1 / wave_shl:1 (no LDS).
+//   * argmin: all values are pre-scaled by 2^KSH and every window is made to contain exactly one
+//     column whose C carries the bias d, so the window sum IS the key (SAD << KSH) | d; the
+//     first-minimum rule (strict '<', sad.go:79) is then a plain unsigned min (v_min3_u32).
+//   * waves merge their per-pixel minima with ds_min_u32 into a row buffer in LDS; after the
+//     one barrier per row the workgroup converts key -> d -> best*255/D (LUT) and stores u8.
+//   * image rows stream through an LDS ring (2h+3 rows, u32 pre-shifted pixels), prefetched one
+//     row ahead through registers.
 #include "sadhip_kernels.h"
+
 namespace sadhip {
-bool fast_supported(const Job&) { return false; }
-hipError_t launch_fast(const Job& j, hipStream_t s) { return launch_generic(j, s); }
+
+namespace {
+
+struct CwArgs {
+  Job j;
+  int nw;          // waves per workgroup (disparity chunks)
+  int ksh;         // key shift: 2^ksh > maxdisp
+  int dpad;        // columns of R kept left of the tile (>= nw*ND, multiple of 4)
+  int tx0;         // origin of tile 0 (<= 0, == w mod P)
+  int tile0;       // first tile index launched (blockIdx.x + tile0)
+  int th;          // output rows per strip
+};
+
+constexpr unsigned KEY_INVALID = 0xffffffffu;
+
+// |a - b| + acc in one instruction.  Inline asm: left to itself hipcc canonicalises the C++
+// form into v_max_u32 + v_min_u32 + v_sub/v_add3 (3 ops) inside the unrolled update.
+__device__ __forceinline__ unsigned absdiff_acc(unsigned a, unsigned b, unsigned acc)
+{
+  unsigned d;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+  return d;
 }
+__device__ __forceinline__ unsigned absdiff(unsigned a, unsigned b)
+{
+  unsigned d;
+  asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ unsigned from_left(unsigned v)     // lane l <- lane l-1 (lane 0: 0)
+{
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);    // wave_shr:1 bound_ctrl:0
+}
+__device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane l+1 (lane 63: 0)
+{
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
+}
+
+template <int P, int ND, int H>
+struct Cw {
+  static_assert(H >= 1 && H <= P, "halo must fit in the neighbour lane");
+  static constexpr int TW = 64 * P;                 // columns per tile
+  static constexpr int OL = P * ((H + P - 1) / P);  // first output column inside the tile
+  static constexpr int STEP = TW - 2 * OL;          // output columns per tile
+  static constexpr int B1 = 2 * H + 1;              // window width
+  static constexpr int NR = 2 * H + 3;              // ring rows (window + leaving row + prefetch)
+  static constexpr int NRV = P + ND - 1;            // R values a lane needs per row
+
+  // ---- horizontal window sums + key minimum for one row --------------------------------------
+  template <bool MASK>
+  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][ND], const int (&jlim)[P],
+                                                    unsigned (&best)[P])
+  {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      unsigned ps[P + 1];
+      ps[0] = 0;
+#pragma unroll
+      for (int k = 0; k < P; ++k) ps[k + 1] = ps[k] + C[k][j];
+      const unsigned T = ps[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int a = p - H, b = p + H;
+        const int lo = a > 0 ? a : 0, hi = b < P - 1 ? b : P - 1;
+        unsigned s = ps[hi + 1] - ps[lo];
+        if (a < 0) s += from_left(T - ps[P + a]);          // last (-a) columns of the left lane
+        if (b > P - 1) s += from_right(ps[b - P + 1]);     // first (b-P+1) columns of the right lane
+        if (MASK) s = (j > jlim[p]) ? KEY_INVALID : s;     // d > min(D, x-h): not a candidate
+        best[p] = s < best[p] ? s : best[p];
+      }
+    }
+  }
+
+  static __device__ void run(const CwArgs& a)
+  {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+    const Job& j = a.j;
+    const int nt = blockDim.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dc = wv * ND;                               // first disparity of this wave
+    const int RW = TW + a.dpad;                           // R values per ring row
+    const int ROWW = TW + RW;                             // u32 per ring row (L then R)
+    unsigned* ring = smem;                                // (NR + 1) rows; row NR stays zero
+    unsigned* rowbest = smem + (NR + 1) * ROWW;           // [2][TW]
+    unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + 2 * TW);   // [maxdisp+1]
+
+    const int tile = blockIdx.x + a.tile0;
+    const int tx = a.tx0 + tile * STEP;                   // image column of lane 0, p 0
+    const int f = blockIdx.z;
+    const uint8_t* __restrict__ Lg = j.left + (size_t)f * j.left_frame_stride;
+    const uint8_t* __restrict__ Rg = j.right + (size_t)f * j.right_frame_stride;
+    uint8_t* __restrict__ Og = j.out + (size_t)f * j.out_frame_stride;
+
+    const int ys = j.y0 + blockIdx.y * a.th;              // strip rows [ys, ye)
+    const int ye = min(ys + a.th, j.y1);
+    // output columns of this tile (tile 0 also owns everything left of its interior)
+    const int ox0 = max(tile == 0 ? j.x0 : tx + OL, j.x0);
+    const int ox1 = min(tx + OL + STEP, j.x1);
+    if (ys >= ye || ox0 >= ox1) return;
+
+    // ---- one-time setup: zero row, row-best buffers, output LUT ------------------------------
+    for (int i = tid; i < ROWW; i += nt) ring[NR * ROWW + i] = 0;
+    for (int i = tid; i < 2 * TW; i += nt) rowbest[i] = KEY_INVALID;
+    for (int i = tid; i <= j.maxdisp; i += nt)
+      lut[i] = (unsigned char)(j.raw ? min(i, 255) : (i * 255) / j.maxdisp);     // sad.go:91-93
+
+    // ---- ring loader: image row yy -> slot, pixels pre-shifted by ksh, zeros outside the image
+    constexpr int MAXV = 3;                               // register-prefetched values per thread
+    const int nvals = ROWW;
+    auto fetch = [&](int yy, int i) -> unsigned {         // value i of ring row for image row yy
+      const bool isR = i >= TW;
+      const int col = isR ? tx - a.dpad + (i - TW) : tx + i;
+      if (yy < 0 || yy >= j.h || col < 0 || col >= j.w) return 0u;
+      const uint8_t* base = isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride;
+      return (unsigned)base[col] << a.ksh;
+    };
+    auto slot_of = [&](int yy) -> int { int s = (yy - (ys - H)) % NR; return s < 0 ? s + NR : s; };
+    auto load_row_sync = [&](int yy) {
+      unsigned* dst = ring + slot_of(yy) * ROWW;
+      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(yy, i);
+    };
+
+    // ---- per-lane state ----------------------------------------------------------------------
+    const int x0 = tx + P * lane;                         // first column of this lane
+    const bool lane_valid = x0 < j.w;                     // (w - tx) % P == 0: all-or-nothing
+    unsigned C[P][ND];
+    int jlim[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int col = x0 + p;
+      const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
+      jlim[p] = min(j.maxdisp, max(0, col - H)) - dc;     // candidate j valid iff j <= jlim[p]
+#pragma unroll
+      for (int q = 0; q < ND; ++q) C[p][q] = biased ? (unsigned)(dc + q) : 0u;
+    }
+    // is any (pixel, d) of this wave outside the candidate range?  (wave-uniform)
+    const bool need_mask = (dc + ND - 1 > j.maxdisp) || (max(ox0, 0) - H < dc + ND - 1);
+
+    const int lofs = P * lane;                                        // L values of this lane
+    const int rofs = TW + a.dpad - dc - (ND - 1) + P * lane;          // R value m=0 of this lane
+
+    // first window row resident before the loop
+    load_row_sync(ys - H);
+    __syncthreads();
+
+    const int nsteps = (ye - ys) + 2 * H;
+    for (int t = 0; t < nsteps; ++t) {
+      const int yin = ys - H + t;                         // row entering the window
+      const int yout = yin - B1;                          // row leaving it (valid once t > 2H)
+      const int y = yin - H;                              // output row of this step (t >= 2H)
+      const bool have_next = t + 1 < nsteps;
+
+      // prefetch the next entering row into registers
+      unsigned pf[MAXV];
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int i = tid + v * nt;
+        pf[v] = (have_next && i < nvals) ? fetch(yin + 1, i) : 0u;
+      }
+
+      // vertical update of the column sums
+      const unsigned* rin = ring + slot_of(yin) * ROWW;
+      const unsigned* rout = ring + (t > 2 * H ? slot_of(yout) : NR) * ROWW;
+      if (lane_valid) {
+        {                                                 // + |L-R| of the entering row
+          unsigned li[P], ri[NRV];
+#pragma unroll
+          for (int p = 0; p < P; ++p) li[p] = rin[lofs + p];
+#pragma unroll
+          for (int m = 0; m < NRV; ++m) ri[m] = rin[rofs + m];
+#pragma unroll
+          for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int q = 0; q < ND; ++q) C[p][q] = absdiff_acc(li[p], ri[p + ND - 1 - q], C[p][q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                // keep the two operand sets from overlapping
+        {                                                 // - |L-R| of the leaving row
+          unsigned lo[P], ro[NRV];
+#pragma unroll
+          for (int p = 0; p < P; ++p) lo[p] = rout[lofs + p];
+#pragma unroll
+          for (int m = 0; m < NRV; ++m) ro[m] = rout[rofs + m];
+#pragma unroll
+          for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int q = 0; q < ND; ++q) C[p][q] -= absdiff(lo[p], ro[p + ND - 1 - q]);
+        }
+      }
+
+      if (t >= 2 * H) {
+        unsigned best[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
+        if (need_mask) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) asm volatile("" : "+v"(jlim[p]));   // keep the compares in the loop
+          reduce_row<true>(C, jlim, best);
+        }
+        else reduce_row<false>(C, jlim, best);
+        unsigned* rb = rowbest + (t & 1) * TW + lofs;
+#pragma unroll
+        for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]);          // ds_min_u32
+      }
+
+      // land the prefetched row (its slot held row yout-1, last read in the previous step)
+      if (have_next) {
+        unsigned* dst = ring + slot_of(yin + 1) * ROWW;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+          const int i = tid + v * nt;
+          if (i < nvals) dst[i] = pf[v];
+        }
+        for (int i = tid + MAXV * nt; i < nvals; i += nt) dst[i] = fetch(yin + 1, i);   // tiny workgroups
+      }
+      __syncthreads();
+
+      if (t >= 2 * H) {                                   // key -> d -> u8, reset the row buffer
+        unsigned* rb = rowbest + (t & 1) * TW;
+        uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride - j.ox;
+        for (int x = ox0 + tid; x < ox1; x += nt) {
+          const unsigned key = rb[x - tx];
+          rb[x - tx] = KEY_INVALID;
+          orow[x] = lut[key & ((1u << a.ksh) - 1u)];
+        }
+      }
+    }
+  }
+};
+
+template <int P, int ND, int H>
+__global__ void __launch_bounds__(1024) k_colwave(CwArgs a) { Cw<P, ND, H>::run(a); }
+
+struct Plan { int nd, nw; };
+
+// chunk size / wave count covering D+1 candidates with the least idle slots (ties: larger ND)
+Plan plan_for(int maxdisp)
+{
+  const int cands = maxdisp + 1;
+  Plan best{0, 0};
+  int best_waste = 1 << 30;
+  const int nds[] = {13, 11, 9};
+  for (int nd : nds) {
+    const int nw = (cands + nd - 1) / nd;
+    if (nw > 16) continue;
+    const int waste = nw * nd - cands;
+    if (waste < best_waste) { best_waste = waste; best = Plan{nd, nw}; }
+  }
+  return best;
+}
+
+template <int P, int ND, int H>
+hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
+{
+  using K = Cw<P, ND, H>;
+  CwArgs a{};
+  a.j = j;
+  a.nw = pl.nw;
+  a.ksh = 32 - __builtin_clz((unsigned)j.maxdisp);            // 2^ksh > maxdisp
+  a.dpad = (pl.nw * ND + 3) & ~3;
+  const int r = j.w % P;
+  a.tx0 = r == 0 ? 0 : r - P;
+  // tiles whose output range meets [x0, x1)
+  int k0 = 0, k1 = 0;
+  while (a.tx0 + (k0 + 1) * K::STEP + K::OL <= j.x0) ++k0;   // tile k0 ends after x0
+  k1 = k0;
+  while (a.tx0 + (k1 + 1) * K::STEP + K::OL < j.x1) ++k1;
+  const int ntiles = k1 - k0 + 1;
+  a.tile0 = k0;
+  const int rows = j.y1 - j.y0;
+  // strip height: enough workgroups to fill 256 CUs a few times over, else as tall as possible
+  const long want = 2048;
+  long nstrips = (want + (long)ntiles * j.n - 1) / ((long)ntiles * j.n);
+  const long max_strips = (rows + 15) / 16;
+  if (nstrips > max_strips) nstrips = max_strips;
+  if (nstrips < 1) nstrips = 1;
+  a.th = (int)((rows + nstrips - 1) / nstrips);
+  nstrips = (rows + a.th - 1) / a.th;
+  const int ROWW = 2 * K::TW + a.dpad;
+  const size_t lds = (size_t)((K::NR + 1) * ROWW + 2 * K::TW) * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15);
+  for (int f0 = 0; f0 < j.n; f0 += 32768) {
+    CwArgs aa = a;
+    aa.j.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
+    aa.j.left += (size_t)f0 * j.left_frame_stride;
+    aa.j.right += (size_t)f0 * j.right_frame_stride;
+    aa.j.out += (size_t)f0 * j.out_frame_stride;
+    hipLaunchKernelGGL((k_colwave<P, ND, H>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+template <int P, int ND>
+hipError_t launch_h(const Job& j, const Plan& pl, int h, hipStream_t s)
+{
+  switch (h) {
+    case 1: return launch_t<P, ND, 1>(j, pl, s);
+    case 2: return launch_t<P, ND, 2>(j, pl, s);
+    case 3: return launch_t<P, ND, 3>(j, pl, s);
+    case 4: return launch_t<P, ND, 4>(j, pl, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+bool fast_supported(const Job& j)
+{
+  const int h = j.block / 2;
+  if (h < 1 || h > 4) return false;                 // BlockSize 2..9 (window 3..9)
+  if (j.maxdisp < 1 || plan_for(j.maxdisp).nw == 0) return false;   // up to 16 waves x 13 disparities
+  if (j.w < 1 || j.h < 1) return false;
+  return true;
+}
+
+hipError_t launch_fast(const Job& j, hipStream_t s)
+{
+  if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
+  const Plan pl = plan_for(j.maxdisp);
+  const int h = j.block / 2;
+  switch (pl.nd) {
+    case 13: return launch_h<4, 13>(j, pl, h, s);
+    case 11: return launch_h<4, 11>(j, pl, h, s);
+    case 9:  return launch_h<4, 9>(j, pl, h, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace sadhip

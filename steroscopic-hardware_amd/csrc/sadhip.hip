@@ -387,7 +387,7 @@ extern "C" int sadhip_disparity_dev_u8(sadhip_ctx* ctx, int n,
   j.n = n; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
   j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.ox = 0; j.oy = 0;
   j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
-  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->slot[0].stream;
+  hipStream_t s = (hipStream_t)hip_stream;   // NULL = HIP's null stream (torch's default stream)
   HIPTRY(dispatch(j, flags, s));
   return SADHIP_OK;
 }
