@@ -9,9 +9,9 @@
 //     wave-instruction, plain v_add/v_sub ~2.3, v_qsad_pk_u16_u8 is quarter rate; one LDS dword
 //     per lane costs as much as two such VALU ops.  So: every |L-R| is one v_sad_u32 with the
 //     accumulate folded in, everything else is adds/subs, and operands stay in registers.
-//   * lane l of a wave owns P adjacent columns; a wave owns ND consecutive disparities for its
-//     64*P columns; the NW waves of a workgroup split the disparity range of one tile.
-//   * vertical: each lane keeps the column sums C[p][j] of its (column, disparity) pairs in
+//   * lane l of a wave owns P=4 adjacent columns; a wave owns ND consecutive disparities for its
+//     256 columns; the NW waves of a workgroup split the disparity range of one tile.
+//   * vertical: each lane keeps the column sums C[p][q] of its (column, disparity) pairs in
 //     registers and slides them down the strip: + |L-R| of the row entering the window (v_sad_u32
 //     with accumulator), - |L-R| of the row leaving it (v_sad_u32 + v_sub).
 //   * horizontal: the (2h+1)-wide window sum of C is formed from in-lane prefix sums plus 2h
@@ -21,9 +21,13 @@
 //     first-minimum rule (strict '<', sad.go:79) is then a plain unsigned min (v_min3_u32).
 //   * waves merge their per-pixel minima with ds_min_u32 into a row buffer in LDS; after the
 //     one barrier per row the workgroup converts key -> d -> best*255/D (LUT) and stores u8.
-//   * image rows stream through an LDS ring (2h+3 rows, u32 pre-shifted pixels), prefetched one
-//     row ahead through registers.
+//   * image rows stream through an LDS ring (2h+3 rows of u32 pre-shifted pixels), prefetched
+//     one row ahead through registers.  ND is a multiple of 4 and the R part of a ring row is
+//     offset so that every lane's operands are 16-byte aligned: all operand reads are
+//     ds_read_b128, which is bank-conflict free at a lane stride of 16 bytes (a ds_read_b32 at
+//     that stride is a 4-way conflict: measured 72 % of LDS cycles).
 #include "sadhip_kernels.h"
+#include <cstdlib>
 
 namespace sadhip {
 
@@ -33,21 +37,20 @@ struct CwArgs {
   Job j;
   int nw;          // waves per workgroup (disparity chunks)
   int ksh;         // key shift: 2^ksh > maxdisp
-  int dpad;        // columns of R kept left of the tile (>= nw*ND, multiple of 4)
+  int dpad;        // columns of R kept left of the tile: nw*ND - 1 (== 3 mod 4)
   int tx0;         // origin of tile 0 (<= 0, == w mod P)
   int tile0;       // first tile index launched (blockIdx.x + tile0)
   int th;          // output rows per strip
+  int dbg;         // tuning aid (SADHIP_TUNE_DBG): 1 skip column update, 2 skip row reduce, 4 skip finalize, 8 skip prefetch
 };
 
 constexpr unsigned KEY_INVALID = 0xffffffffu;
 
-// |a - b| + acc in one instruction.  Inline asm: left to itself hipcc canonicalises the C++
-// form into v_max_u32 + v_min_u32 + v_sub/v_add3 (3 ops) inside the unrolled update.
-__device__ __forceinline__ unsigned absdiff_acc(unsigned a, unsigned b, unsigned acc)
+// |a - b| + acc in one instruction, in place.  Inline asm: left to itself hipcc canonicalises the
+// C++ form into v_max_u32 + v_min_u32 + v_sub/v_add3 (3 ops) inside the unrolled update.
+__device__ __forceinline__ void sad_acc(unsigned& acc, unsigned a, unsigned b)
 {
-  unsigned d;
-  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
-  return d;
+  asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ unsigned absdiff(unsigned a, unsigned b)
 {
@@ -64,15 +67,54 @@ __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane 
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
 }
 
-template <int P, int ND, int H>
+template <int ND, int H>
 struct Cw {
+  static constexpr int P = 4;                       // columns per lane (one ds_read_b128 of L)
   static_assert(H >= 1 && H <= P, "halo must fit in the neighbour lane");
+  static_assert(ND % 4 == 0, "ND must keep every lane's R operands 16-byte aligned");
   static constexpr int TW = 64 * P;                 // columns per tile
   static constexpr int OL = P * ((H + P - 1) / P);  // first output column inside the tile
   static constexpr int STEP = TW - 2 * OL;          // output columns per tile
   static constexpr int B1 = 2 * H + 1;              // window width
   static constexpr int NR = 2 * H + 3;              // ring rows (window + leaving row + prefetch)
-  static constexpr int NRV = P + ND - 1;            // R values a lane needs per row
+  static constexpr int NRV = P + ND;                // R values a lane loads per row (last one unused)
+
+  // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
+  // lin/lout: this lane's 4 L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
+  static __device__ __forceinline__ void update_columns(unsigned (&C)[P][ND],
+                                                        const uint4* lin, const uint4* rin,
+                                                        const uint4* lout, const uint4* rout)
+  {
+    {
+      unsigned li[P], ri[NRV];
+      const uint4 l4 = lin[0];
+      li[0] = l4.x; li[1] = l4.y; li[2] = l4.z; li[3] = l4.w;
+#pragma unroll
+      for (int m = 0; m < NRV / 4; ++m) {
+        const uint4 r4 = rin[m];
+        ri[4 * m] = r4.x; ri[4 * m + 1] = r4.y; ri[4 * m + 2] = r4.z; ri[4 * m + 3] = r4.w;
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < ND; ++q) sad_acc(C[p][q], li[p], ri[p + ND - 1 - q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);                    // keep the two operand sets from overlapping
+    {
+      unsigned lo[P], ro[NRV];
+      const uint4 l4 = lout[0];
+      lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z; lo[3] = l4.w;
+#pragma unroll
+      for (int m = 0; m < NRV / 4; ++m) {
+        const uint4 r4 = rout[m];
+        ro[4 * m] = r4.x; ro[4 * m + 1] = r4.y; ro[4 * m + 2] = r4.z; ro[4 * m + 3] = r4.w;
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < ND; ++q) C[p][q] -= absdiff(lo[p], ro[p + ND - 1 - q]);
+    }
+  }
 
   // ---- horizontal window sums + key minimum for one row --------------------------------------
   template <bool MASK>
@@ -80,11 +122,11 @@ struct Cw {
                                                     unsigned (&best)[P])
   {
 #pragma unroll
-    for (int j = 0; j < ND; ++j) {
+    for (int q = 0; q < ND; ++q) {
       unsigned ps[P + 1];
       ps[0] = 0;
 #pragma unroll
-      for (int k = 0; k < P; ++k) ps[k + 1] = ps[k] + C[k][j];
+      for (int k = 0; k < P; ++k) ps[k + 1] = ps[k] + C[k][q];
       const unsigned T = ps[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -92,8 +134,9 @@ struct Cw {
         const int lo = a > 0 ? a : 0, hi = b < P - 1 ? b : P - 1;
         unsigned s = ps[hi + 1] - ps[lo];
         if (a < 0) s += from_left(T - ps[P + a]);          // last (-a) columns of the left lane
+        if (a < 0 && b > P - 1) asm("" : "+v"(s));         // two v_add_u32_dpp, not v_mov_dpp x2 + v_add3
         if (b > P - 1) s += from_right(ps[b - P + 1]);     // first (b-P+1) columns of the right lane
-        if (MASK) s = (j > jlim[p]) ? KEY_INVALID : s;     // d > min(D, x-h): not a candidate
+        if (MASK) s = (q > jlim[p]) ? KEY_INVALID : s;     // d > min(D, x-h): not a candidate
         best[p] = s < best[p] ? s : best[p];
       }
     }
@@ -108,8 +151,8 @@ struct Cw {
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dc = wv * ND;                               // first disparity of this wave
-    const int RW = TW + a.dpad;                           // R values per ring row
-    const int ROWW = TW + RW;                             // u32 per ring row (L then R)
+    const int RW = TW + a.dpad + 1;                       // R values per ring row (multiple of 4)
+    const int ROWW = TW + RW;                             // u32 per ring row: L[TW] then R[RW]
     unsigned* ring = smem;                                // (NR + 1) rows; row NR stays zero
     unsigned* rowbest = smem + (NR + 1) * ROWW;           // [2][TW]
     unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + 2 * TW);   // [maxdisp+1]
@@ -134,20 +177,30 @@ struct Cw {
     for (int i = tid; i <= j.maxdisp; i += nt)
       lut[i] = (unsigned char)(j.raw ? min(i, 255) : (i * 255) / j.maxdisp);     // sad.go:91-93
 
-    // ---- ring loader: image row yy -> slot, pixels pre-shifted by ksh, zeros outside the image
+    // ---- ring loader.  A ring row holds L columns [tx, tx+TW) then R columns [tx-dpad, tx+TW),
+    //      as u32 pixels shifted by ksh, zero outside the image.  Element i of a row is fetched by
+    //      thread i % nt in prefetch slot i / nt.  Everything that does not depend on the row is
+    //      hoisted here: clamped column, validity mask, and whether the slot reads L or R (uniform
+    //      per wave because TW is a multiple of 64), so the loop issues bare scalar-base loads.
     constexpr int MAXV = 3;                               // register-prefetched values per thread
     const int nvals = ROWW;
-    auto fetch = [&](int yy, int i) -> unsigned {         // value i of ring row for image row yy
+    int pcol[MAXV];                                       // clamped image column
+    unsigned pmask[MAXV];                                 // 0xff when the column exists, else 0
+    bool pisR[MAXV];
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int i = tid + v * nt;
+      pisR[v] = (wv * 64 + v * nt) >= TW;                 // wave-uniform
+      const int col = pisR[v] ? tx - a.dpad + (i - TW) : tx + i;
+      pmask[v] = (i < nvals && col >= 0 && col < j.w) ? 0xffu : 0u;
+      pcol[v] = min(max(col, 0), j.w - 1);
+    }
+    auto fetch = [&](int yy, int i) -> unsigned {         // generic element fetch (setup / tiny workgroups)
       const bool isR = i >= TW;
       const int col = isR ? tx - a.dpad + (i - TW) : tx + i;
       if (yy < 0 || yy >= j.h || col < 0 || col >= j.w) return 0u;
       const uint8_t* base = isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride;
-      return (unsigned)base[col] << a.ksh;
-    };
-    auto slot_of = [&](int yy) -> int { int s = (yy - (ys - H)) % NR; return s < 0 ? s + NR : s; };
-    auto load_row_sync = [&](int yy) {
-      unsigned* dst = ring + slot_of(yy) * ROWW;
-      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(yy, i);
+      return (unsigned)base[col];
     };
 
     // ---- per-lane state ----------------------------------------------------------------------
@@ -159,65 +212,56 @@ struct Cw {
     for (int p = 0; p < P; ++p) {
       const int col = x0 + p;
       const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
-      jlim[p] = min(j.maxdisp, max(0, col - H)) - dc;     // candidate j valid iff j <= jlim[p]
+      jlim[p] = min(j.maxdisp, max(0, col - H)) - dc;     // candidate q valid iff q <= jlim[p]
 #pragma unroll
       for (int q = 0; q < ND; ++q) C[p][q] = biased ? (unsigned)(dc + q) : 0u;
     }
     // is any (pixel, d) of this wave outside the candidate range?  (wave-uniform)
     const bool need_mask = (dc + ND - 1 > j.maxdisp) || (max(ox0, 0) - H < dc + ND - 1);
 
-    const int lofs = P * lane;                                        // L values of this lane
-    const int rofs = TW + a.dpad - dc - (ND - 1) + P * lane;          // R value m=0 of this lane
+    // this lane's operands inside a ring row (u32 index): L at lofs, R value m at rofs + m
+    const int lofs = P * lane;
+    const int rofs = TW + (a.dpad - dc - (ND - 1)) + P * lane;        // multiple of 4 by construction
 
-    // first window row resident before the loop
-    load_row_sync(ys - H);
+    {                                                     // first window row resident before the loop
+      unsigned* dst = ring;                               // row ys-H lives in slot 0
+      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(ys - H, i) << a.ksh;
+    }
     __syncthreads();
 
+    // ring slots advance by one per step: row ys-H+t lives in slot t % NR
+    int slot_in = 0;                                      // slot of the entering row
     const int nsteps = (ye - ys) + 2 * H;
     for (int t = 0; t < nsteps; ++t) {
       const int yin = ys - H + t;                         // row entering the window
-      const int yout = yin - B1;                          // row leaving it (valid once t > 2H)
       const int y = yin - H;                              // output row of this step (t >= 2H)
       const bool have_next = t + 1 < nsteps;
+      const int slot_next = slot_in + 1 == NR ? 0 : slot_in + 1;
+      // the leaving row yin-B1 sits NR-B1 = 2 slots ahead; before the window is full: the zero row
+      const int slot_out = t > 2 * H ? (slot_in + 2 >= NR ? slot_in + 2 - NR : slot_in + 2) : NR;
 
-      // prefetch the next entering row into registers
+      // prefetch the next entering row into registers (raw bytes; landed at the end of the step)
       unsigned pf[MAXV];
+      const int yn = yin + 1;
+      const bool row_ok = have_next && yn >= 0 && yn < j.h && !(a.dbg & 8);       // uniform
+      if (row_ok) {
+        const uint8_t* lrow = Lg + (size_t)(yn - j.row0) * j.lstride;
+        const uint8_t* rrow = Rg + (size_t)(yn - j.row0) * j.rstride;
 #pragma unroll
-      for (int v = 0; v < MAXV; ++v) {
-        const int i = tid + v * nt;
-        pf[v] = (have_next && i < nvals) ? fetch(yin + 1, i) : 0u;
+        for (int v = 0; v < MAXV; ++v) pf[v] = (pisR[v] ? rrow : lrow)[pcol[v]];
+      } else {
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) pf[v] = 0u;
       }
 
       // vertical update of the column sums
-      const unsigned* rin = ring + slot_of(yin) * ROWW;
-      const unsigned* rout = ring + (t > 2 * H ? slot_of(yout) : NR) * ROWW;
-      if (lane_valid) {
-        {                                                 // + |L-R| of the entering row
-          unsigned li[P], ri[NRV];
-#pragma unroll
-          for (int p = 0; p < P; ++p) li[p] = rin[lofs + p];
-#pragma unroll
-          for (int m = 0; m < NRV; ++m) ri[m] = rin[rofs + m];
-#pragma unroll
-          for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int q = 0; q < ND; ++q) C[p][q] = absdiff_acc(li[p], ri[p + ND - 1 - q], C[p][q]);
-        }
-        __builtin_amdgcn_sched_barrier(0);                // keep the two operand sets from overlapping
-        {                                                 // - |L-R| of the leaving row
-          unsigned lo[P], ro[NRV];
-#pragma unroll
-          for (int p = 0; p < P; ++p) lo[p] = rout[lofs + p];
-#pragma unroll
-          for (int m = 0; m < NRV; ++m) ro[m] = rout[rofs + m];
-#pragma unroll
-          for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int q = 0; q < ND; ++q) C[p][q] -= absdiff(lo[p], ro[p + ND - 1 - q]);
-        }
-      }
+      const unsigned* rin = ring + slot_in * ROWW;
+      const unsigned* rout = ring + slot_out * ROWW;
+      if (lane_valid && !(a.dbg & 1))
+        update_columns(C, reinterpret_cast<const uint4*>(rin + lofs), reinterpret_cast<const uint4*>(rin + rofs),
+                       reinterpret_cast<const uint4*>(rout + lofs), reinterpret_cast<const uint4*>(rout + rofs));
 
-      if (t >= 2 * H) {
+      if (t >= 2 * H && !(a.dbg & 2)) {
         unsigned best[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
@@ -225,8 +269,9 @@ struct Cw {
 #pragma unroll
           for (int p = 0; p < P; ++p) asm volatile("" : "+v"(jlim[p]));   // keep the compares in the loop
           reduce_row<true>(C, jlim, best);
+        } else {
+          reduce_row<false>(C, jlim, best);
         }
-        else reduce_row<false>(C, jlim, best);
         unsigned* rb = rowbest + (t & 1) * TW + lofs;
 #pragma unroll
         for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]);          // ds_min_u32
@@ -234,17 +279,17 @@ struct Cw {
 
       // land the prefetched row (its slot held row yout-1, last read in the previous step)
       if (have_next) {
-        unsigned* dst = ring + slot_of(yin + 1) * ROWW;
+        unsigned* dst = ring + slot_next * ROWW;
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
           const int i = tid + v * nt;
-          if (i < nvals) dst[i] = pf[v];
+          if (i < nvals) dst[i] = (pf[v] & pmask[v]) << a.ksh;
         }
-        for (int i = tid + MAXV * nt; i < nvals; i += nt) dst[i] = fetch(yin + 1, i);   // tiny workgroups
+        for (int i = tid + MAXV * nt; i < nvals; i += nt) dst[i] = fetch(yn, i) << a.ksh;   // tiny workgroups
       }
       __syncthreads();
 
-      if (t >= 2 * H) {                                   // key -> d -> u8, reset the row buffer
+      if (t >= 2 * H && !(a.dbg & 4)) {                   // key -> d -> u8, reset the row buffer
         unsigned* rb = rowbest + (t & 1) * TW;
         uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride - j.ox;
         for (int x = ox0 + tid; x < ox1; x += nt) {
@@ -253,40 +298,45 @@ struct Cw {
           orow[x] = lut[key & ((1u << a.ksh) - 1u)];
         }
       }
+      slot_in = slot_next;
     }
   }
 };
 
-template <int P, int ND, int H>
-__global__ void __launch_bounds__(1024) k_colwave(CwArgs a) { Cw<P, ND, H>::run(a); }
+template <int ND, int H>
+__global__ void __launch_bounds__(1024) k_colwave(CwArgs a) { Cw<ND, H>::run(a); }
 
 struct Plan { int nd, nw; };
 
-// chunk size / wave count covering D+1 candidates with the least idle slots (ties: larger ND)
+// chunk size / wave count covering D+1 candidates with the least idle slots (ties: ND = 12)
 Plan plan_for(int maxdisp)
 {
   const int cands = maxdisp + 1;
   Plan best{0, 0};
   int best_waste = 1 << 30;
-  const int nds[] = {13, 11, 9};
+  const int nds[] = {16, 12, 8};
+  const char* force = getenv("SADHIP_TUNE_ND");                 // tuning aid: force a chunk size
   for (int nd : nds) {
+    if (force && atoi(force) != nd) continue;
     const int nw = (cands + nd - 1) / nd;
     if (nw > 16) continue;
     const int waste = nw * nd - cands;
-    if (waste < best_waste) { best_waste = waste; best = Plan{nd, nw}; }
+    if (waste < best_waste || (waste == best_waste && nd == 12)) { best_waste = waste; best = Plan{nd, nw}; }
   }
   return best;
 }
 
-template <int P, int ND, int H>
+template <int ND, int H>
 hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
 {
-  using K = Cw<P, ND, H>;
+  using K = Cw<ND, H>;
+  constexpr int P = K::P;
   CwArgs a{};
   a.j = j;
   a.nw = pl.nw;
   a.ksh = 32 - __builtin_clz((unsigned)j.maxdisp);            // 2^ksh > maxdisp
-  a.dpad = (pl.nw * ND + 3) & ~3;
+  { const char* e = getenv("SADHIP_TUNE_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.dpad = pl.nw * ND - 1;                                    // == 3 (mod 4): lane operands 16-B aligned
   const int r = j.w % P;
   a.tx0 = r == 0 ? 0 : r - P;
   // tiles whose output range meets [x0, x1)
@@ -298,14 +348,15 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
   // strip height: enough workgroups to fill 256 CUs a few times over, else as tall as possible
-  const long want = 2048;
+  const char* want_env = getenv("SADHIP_TUNE_WGS");           // tuning aid: target workgroup count
+  const long want = want_env ? atol(want_env) : 2048;
   long nstrips = (want + (long)ntiles * j.n - 1) / ((long)ntiles * j.n);
   const long max_strips = (rows + 15) / 16;
   if (nstrips > max_strips) nstrips = max_strips;
   if (nstrips < 1) nstrips = 1;
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
-  const int ROWW = 2 * K::TW + a.dpad;
+  const int ROWW = 2 * K::TW + a.dpad + 1;
   const size_t lds = (size_t)((K::NR + 1) * ROWW + 2 * K::TW) * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15);
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     CwArgs aa = a;
@@ -313,21 +364,21 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
     aa.j.left += (size_t)f0 * j.left_frame_stride;
     aa.j.right += (size_t)f0 * j.right_frame_stride;
     aa.j.out += (size_t)f0 * j.out_frame_stride;
-    hipLaunchKernelGGL((k_colwave<P, ND, H>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<ND, H>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
 
-template <int P, int ND>
+template <int ND>
 hipError_t launch_h(const Job& j, const Plan& pl, int h, hipStream_t s)
 {
   switch (h) {
-    case 1: return launch_t<P, ND, 1>(j, pl, s);
-    case 2: return launch_t<P, ND, 2>(j, pl, s);
-    case 3: return launch_t<P, ND, 3>(j, pl, s);
-    case 4: return launch_t<P, ND, 4>(j, pl, s);
+    case 1: return launch_t<ND, 1>(j, pl, s);
+    case 2: return launch_t<ND, 2>(j, pl, s);
+    case 3: return launch_t<ND, 3>(j, pl, s);
+    case 4: return launch_t<ND, 4>(j, pl, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -338,7 +389,7 @@ bool fast_supported(const Job& j)
 {
   const int h = j.block / 2;
   if (h < 1 || h > 4) return false;                 // BlockSize 2..9 (window 3..9)
-  if (j.maxdisp < 1 || plan_for(j.maxdisp).nw == 0) return false;   // up to 16 waves x 13 disparities
+  if (j.maxdisp < 1 || plan_for(j.maxdisp).nw == 0) return false;   // up to 16 waves x 16 disparities
   if (j.w < 1 || j.h < 1) return false;
   return true;
 }
@@ -349,9 +400,9 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
   const Plan pl = plan_for(j.maxdisp);
   const int h = j.block / 2;
   switch (pl.nd) {
-    case 13: return launch_h<4, 13>(j, pl, h, s);
-    case 11: return launch_h<4, 11>(j, pl, h, s);
-    case 9:  return launch_h<4, 9>(j, pl, h, s);
+    case 16: return launch_h<16>(j, pl, h, s);
+    case 12: return launch_h<12>(j, pl, h, s);
+    case 8:  return launch_h<8>(j, pl, h, s);
     default: return hipErrorInvalidValue;
   }
 }
