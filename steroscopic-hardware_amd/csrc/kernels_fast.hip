@@ -67,9 +67,9 @@ __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane 
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
 }
 
-template <int ND, int H>
-struct Cw {
-  static constexpr int P = 4;                       // columns per lane (one ds_read_b128 of L)
+template <int P, int ND, int H>
+struct Cw {                                         // P columns per lane: 4 (h <= 4) or 8 (h <= 8)
+  static_assert(P == 4 || P == 8, "operand reads are whole ds_read_b128");
   static_assert(H >= 1 && H <= P, "halo must fit in the neighbour lane");
   static_assert(ND % 4 == 0, "ND must keep every lane's R operands 16-byte aligned");
   static constexpr int TW = 64 * P;                 // columns per tile
@@ -87,8 +87,11 @@ struct Cw {
   {
     {
       unsigned li[P], ri[NRV];
-      const uint4 l4 = lin[0];
-      li[0] = l4.x; li[1] = l4.y; li[2] = l4.z; li[3] = l4.w;
+#pragma unroll
+      for (int m = 0; m < P / 4; ++m) {
+        const uint4 l4 = lin[m];
+        li[4 * m] = l4.x; li[4 * m + 1] = l4.y; li[4 * m + 2] = l4.z; li[4 * m + 3] = l4.w;
+      }
 #pragma unroll
       for (int m = 0; m < NRV / 4; ++m) {
         const uint4 r4 = rin[m];
@@ -102,8 +105,11 @@ struct Cw {
     __builtin_amdgcn_sched_barrier(0);                    // keep the two operand sets from overlapping
     {
       unsigned lo[P], ro[NRV];
-      const uint4 l4 = lout[0];
-      lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z; lo[3] = l4.w;
+#pragma unroll
+      for (int m = 0; m < P / 4; ++m) {
+        const uint4 l4 = lout[m];
+        lo[4 * m] = l4.x; lo[4 * m + 1] = l4.y; lo[4 * m + 2] = l4.z; lo[4 * m + 3] = l4.w;
+      }
 #pragma unroll
       for (int m = 0; m < NRV / 4; ++m) {
         const uint4 r4 = rout[m];
@@ -303,34 +309,36 @@ struct Cw {
   }
 };
 
-template <int ND, int H>
-__global__ void __launch_bounds__(1024) k_colwave(CwArgs a) { Cw<ND, H>::run(a); }
+// P = 4: up to 16 waves (128 VGPRs); P = 8 keeps twice the column sums: up to 12 waves (168 VGPRs)
+template <int P, int ND, int H>
+__global__ void __launch_bounds__(P == 4 ? 1024 : 768) k_colwave(CwArgs a) { Cw<P, ND, H>::run(a); }
 
 struct Plan { int nd, nw; };
 
 // chunk size / wave count covering D+1 candidates with the least idle slots (ties: ND = 12)
-Plan plan_for(int maxdisp)
+Plan plan_for(int maxdisp, int p)
 {
   const int cands = maxdisp + 1;
   Plan best{0, 0};
   int best_waste = 1 << 30;
-  const int nds[] = {16, 12, 8};
+  const int nds[] = {12, 8};
+  const int max_waves = p == 4 ? 16 : 12;
   const char* force = getenv("SADHIP_TUNE_ND");                 // tuning aid: force a chunk size
   for (int nd : nds) {
     if (force && atoi(force) != nd) continue;
+    if (p == 8 && nd != 12) continue;
     const int nw = (cands + nd - 1) / nd;
-    if (nw > 16) continue;
+    if (nw > max_waves) continue;
     const int waste = nw * nd - cands;
     if (waste < best_waste || (waste == best_waste && nd == 12)) { best_waste = waste; best = Plan{nd, nw}; }
   }
   return best;
 }
 
-template <int ND, int H>
+template <int P, int ND, int H>
 hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
 {
-  using K = Cw<ND, H>;
-  constexpr int P = K::P;
+  using K = Cw<P, ND, H>;
   CwArgs a{};
   a.j = j;
   a.nw = pl.nw;
@@ -364,23 +372,18 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
     aa.j.left += (size_t)f0 * j.left_frame_stride;
     aa.j.right += (size_t)f0 * j.right_frame_stride;
     aa.j.out += (size_t)f0 * j.out_frame_stride;
-    hipLaunchKernelGGL((k_colwave<ND, H>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
 
-template <int ND>
-hipError_t launch_h(const Job& j, const Plan& pl, int h, hipStream_t s)
+int cols_per_lane(int h)
 {
-  switch (h) {
-    case 1: return launch_t<ND, 1>(j, pl, s);
-    case 2: return launch_t<ND, 2>(j, pl, s);
-    case 3: return launch_t<ND, 3>(j, pl, s);
-    case 4: return launch_t<ND, 4>(j, pl, s);
-    default: return hipErrorInvalidValue;
-  }
+  const char* force = getenv("SADHIP_TUNE_P");                  // tuning aid: force 4 or 8
+  if (force && (atoi(force) == 4 || atoi(force) == 8) && h <= atoi(force)) return atoi(force);
+  return h <= 4 ? 4 : 8;
 }
 
 }  // namespace
@@ -388,8 +391,8 @@ hipError_t launch_h(const Job& j, const Plan& pl, int h, hipStream_t s)
 bool fast_supported(const Job& j)
 {
   const int h = j.block / 2;
-  if (h < 1 || h > 4) return false;                 // BlockSize 2..9 (window 3..9)
-  if (j.maxdisp < 1 || plan_for(j.maxdisp).nw == 0) return false;   // up to 16 waves x 16 disparities
+  if (h < 1 || h > 8) return false;                 // BlockSize 2..17 (window 3..17)
+  if (j.maxdisp < 1 || plan_for(j.maxdisp, cols_per_lane(h)).nw == 0) return false;
   if (j.w < 1 || j.h < 1) return false;
   return true;
 }
@@ -397,14 +400,15 @@ bool fast_supported(const Job& j)
 hipError_t launch_fast(const Job& j, hipStream_t s)
 {
   if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
-  const Plan pl = plan_for(j.maxdisp);
   const int h = j.block / 2;
-  switch (pl.nd) {
-    case 16: return launch_h<16>(j, pl, h, s);
-    case 12: return launch_h<12>(j, pl, h, s);
-    case 8:  return launch_h<8>(j, pl, h, s);
-    default: return hipErrorInvalidValue;
-  }
+  const int p = cols_per_lane(h);
+  const Plan pl = plan_for(j.maxdisp, p);
+#define SADHIP_CASE(PP, NDD, HH) if (p == PP && pl.nd == NDD && h == HH) return launch_t<PP, NDD, HH>(j, pl, s)
+  SADHIP_CASE(4, 12, 1); SADHIP_CASE(4, 12, 2); SADHIP_CASE(4, 12, 3); SADHIP_CASE(4, 12, 4);
+  SADHIP_CASE(4, 8, 1);  SADHIP_CASE(4, 8, 2);  SADHIP_CASE(4, 8, 3);  SADHIP_CASE(4, 8, 4);
+  SADHIP_CASE(8, 12, 4); SADHIP_CASE(8, 12, 5); SADHIP_CASE(8, 12, 6); SADHIP_CASE(8, 12, 7); SADHIP_CASE(8, 12, 8);
+#undef SADHIP_CASE
+  return hipErrorInvalidValue;
 }
 
 }  // namespace sadhip

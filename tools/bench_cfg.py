@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Times one configuration (device-resident batch) and checks a band against the oracle.
+usage: bench_cfg.py W H BLOCK MAXDISP [NFRAMES]"""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "oracle")]
+import numpy as np, torch
+import steroscopic_hardware_amd as sha, oracle
+W, H, B, D = (int(v) for v in sys.argv[1:5]); N = int(sys.argv[5]) if len(sys.argv) > 5 else 16
+dev = torch.device("cuda", 0)
+Ls, Rs = sha.synth.synth_batch_torch([1000 + i for i in range(N)], W, H, dev)
+out = torch.empty_like(Ls)
+ctx = sha.capi.Context(0, W, H, 1)
+for _ in range(2): ctx.disparity_dev(Ls, Rs, out, B, D)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); K = 5
+for _ in range(K): ctx.disparity_dev(Ls, Rs, out, B, D)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / K / N
+L0, R0 = Ls[0].cpu().numpy(), Rs[0].cpu().numpy()
+y0 = H // 2
+ok = np.array_equal(out[0, y0:y0 + 4].cpu().numpy(), oracle.disparity_closed(L0, R0, B, D, region=(0, y0, W, y0 + 4)))
+ok2 = np.array_equal(out[0, :3].cpu().numpy(), oracle.disparity_closed(L0, R0, B, D, region=(0, 0, W, 3)))
+c = sha.synth.candidates_per_pair(W, H, B, D)
+print(f"{W}x{H} b{B} D{D} n={N} kind={sha.capi.kernel_kind(W,H,B,D)}: {ms*1e3:.1f} us/frame  {c/ms/1e6:.0f} Gcand/s  {3*W*H/ms/1e6:.1f} GB/s  parity={ok and ok2}")
