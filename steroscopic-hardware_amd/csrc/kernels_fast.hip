@@ -52,18 +52,41 @@ __device__ __forceinline__ void sad_acc(unsigned& acc, unsigned a, unsigned b)
 {
   asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ unsigned absdiff(unsigned a, unsigned b)
+// c_i -= |l - r_i| for four disparities in ONE asm statement.  hipcc pads every asm boundary
+// whose registers the next instruction touches with an s_nop, and on this chip an s_nop costs a
+// full issue slot (tools/ubench/block_bench.hip: 46 such pads were 24 % of the update block);
+// four per statement leaves one pad per four candidates and keeps the sad -> sub pairs apart.
+__device__ __forceinline__ void sad_sub4(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
+                                         unsigned l, unsigned r0, unsigned r1, unsigned r2, unsigned r3)
 {
-  unsigned d;
-  asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
-  return d;
+  unsigned t0, t1, t2, t3;
+  asm("v_sad_u32 %4, %8, %9, 0\n\t"
+      "v_sad_u32 %5, %8, %10, 0\n\t"
+      "v_sad_u32 %6, %8, %11, 0\n\t"
+      "v_sad_u32 %7, %8, %12, 0\n\t"
+      "v_sub_u32 %0, %0, %4\n\t"
+      "v_sub_u32 %1, %1, %5\n\t"
+      "v_sub_u32 %2, %2, %6\n\t"
+      "v_sub_u32 %3, %3, %7"
+      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(l), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
 }
 __device__ __forceinline__ unsigned from_left(unsigned v)     // lane l <- lane l-1 (lane 0: 0)
 {
+#if defined(SADHIP_EXP) && SADHIP_EXP == 1
+  return v;                                                    // experiment: no cross-lane move
+#elif defined(SADHIP_EXP) && SADHIP_EXP == 2
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // experiment: row_shr:1
+#endif
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);    // wave_shr:1 bound_ctrl:0
 }
 __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane l+1 (lane 63: 0)
 {
+#if defined(SADHIP_EXP) && SADHIP_EXP == 1
+  return v;
+#elif defined(SADHIP_EXP) && SADHIP_EXP == 2
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);   // experiment: row_shl:1
+#endif
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
 }
 
@@ -118,33 +141,58 @@ struct Cw {                                         // P columns per lane: 4 (h 
 #pragma unroll
       for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int q = 0; q < ND; ++q) C[p][q] -= absdiff(lo[p], ro[p + ND - 1 - q]);
+        for (int q = 0; q < ND; q += 4)
+          sad_sub4(C[p][q], C[p][q + 1], C[p][q + 2], C[p][q + 3], lo[p], ro[p + ND - 1 - q],
+                   ro[p + ND - 2 - q], ro[p + ND - 3 - q], ro[p + ND - 4 - q]);
     }
   }
 
   // ---- horizontal window sums + key minimum for one row --------------------------------------
+  // Per disparity q: stage A = in-lane prefix sums ps[] and the suffix sums the right neighbour
+  // needs; stage B = window sums (DPP adds pulling from both neighbour lanes) folded into best[].
+  // A DPP operand must be written >= 2 instructions before the DPP op reads it, or the compiler
+  // pads with s_nop (a full issue slot each here), so the stages are software-pipelined:
+  // A(q+1) is issued between A(q) and B(q), pinned with sched_barrier.
+  struct Pre { unsigned ps[P + 1]; unsigned suf[P + 1]; };   // suf[k] = sum of the lane's last k columns
+
+  static __device__ __forceinline__ void stage_a(const unsigned (&C)[P][ND], int q, Pre& r)
+  {
+    r.ps[0] = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) r.ps[k + 1] = r.ps[k] + C[k][q];
+#pragma unroll
+    for (int k = 1; k <= H && k <= P; ++k) r.suf[k] = r.ps[P] - r.ps[P - k];
+  }
+
+  template <bool MASK>
+  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const int (&jlim)[P], unsigned (&best)[P])
+  {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int a = p - H, b = p + H;
+      const int lo = a > 0 ? a : 0, hi = b < P - 1 ? b : P - 1;
+      unsigned s = lo == 0 ? r.ps[hi + 1] : r.ps[hi + 1] - r.ps[lo];
+      if (a < 0) s += from_left(r.suf[-a]);                // last (-a) columns of the left lane
+      if (a < 0 && b > P - 1) asm("" : "+v"(s));           // two v_add_u32_dpp, not v_mov_dpp x2 + v_add3
+      if (b > P - 1) s += from_right(r.ps[b - P + 1]);     // first (b-P+1) columns of the right lane
+      if (MASK) s = (q > jlim[p]) ? KEY_INVALID : s;       // d > min(D, x-h): not a candidate
+      best[p] = s < best[p] ? s : best[p];
+    }
+  }
+
   template <bool MASK>
   static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][ND], const int (&jlim)[P],
                                                     unsigned (&best)[P])
   {
+    Pre cur, nxt;
+    stage_a(C, 0, cur);
 #pragma unroll
     for (int q = 0; q < ND; ++q) {
-      unsigned ps[P + 1];
-      ps[0] = 0;
-#pragma unroll
-      for (int k = 0; k < P; ++k) ps[k + 1] = ps[k] + C[k][q];
-      const unsigned T = ps[P];
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int a = p - H, b = p + H;
-        const int lo = a > 0 ? a : 0, hi = b < P - 1 ? b : P - 1;
-        unsigned s = ps[hi + 1] - ps[lo];
-        if (a < 0) s += from_left(T - ps[P + a]);          // last (-a) columns of the left lane
-        if (a < 0 && b > P - 1) asm("" : "+v"(s));         // two v_add_u32_dpp, not v_mov_dpp x2 + v_add3
-        if (b > P - 1) s += from_right(ps[b - P + 1]);     // first (b-P+1) columns of the right lane
-        if (MASK) s = (q > jlim[p]) ? KEY_INVALID : s;     // d > min(D, x-h): not a candidate
-        best[p] = s < best[p] ? s : best[p];
-      }
+      if (q + 1 < ND) stage_a(C, q + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_b<MASK>(cur, q, jlim, best);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
   }
 
@@ -293,7 +341,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
         }
         for (int i = tid + MAXV * nt; i < nvals; i += nt) dst[i] = fetch(yn, i) << a.ksh;   // tiny workgroups
       }
-      __syncthreads();
+      if (!(a.dbg & 16)) __syncthreads();
 
       if (t >= 2 * H && !(a.dbg & 4)) {                   // key -> d -> u8, reset the row buffer
         unsigned* rb = rowbest + (t & 1) * TW;

@@ -124,6 +124,31 @@ KERNEL32(k_pk_max_i16,   "v_pk_max_i16 %0, %1, %0")
 KERNEL32(k_sub_u32_sgpr, "v_sub_u32 %0, %0, s20")
 KERNEL32(k_sad_u8_sgpr,  "v_sad_u8 %0, s20, %2, %0")
 KERNEL32(k_addc_u32,     "v_addc_co_u32 %0, vcc, %1, %0, vcc")
+// same instructions with 24 independent chains per lane (latency vs issue rate)
+#define KERNEL32W(NAME, ASM)                                                     \
+__global__ void __launch_bounds__(256) NAME(unsigned* out, unsigned a, unsigned b) { \
+  unsigned va = a ^ threadIdx.x, vb = b + threadIdx.x * 3u;                      \
+  unsigned c[24];                                                                \
+  _Pragma("unroll") for (int k = 0; k < 24; ++k) c[k] = threadIdx.x + k;         \
+  for (int i = 0; i < ITER * 16 / 24; ++i) {                                     \
+    _Pragma("unroll") for (int k = 0; k < 24; ++k)                               \
+      asm volatile(ASM : "+v"(c[k]) : "v"(va), "v"(vb) : "vcc", "s20", "s21");  \
+  }                                                                              \
+  unsigned r = 0;                                                                \
+  _Pragma("unroll") for (int k = 0; k < 24; ++k) r ^= c[k];                      \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                \
+}
+KERNEL32W(kw_add_u32,    "v_add_u32 %0, %1, %0")
+KERNEL32W(kw_sad_u32,    "v_sad_u32 %0, %1, %2, %0")
+KERNEL32W(kw_sad_u8,     "v_sad_u8 %0, %1, %2, %0")
+KERNEL32W(kw_min3_u32,   "v_min3_u32 %0, %1, %2, %0")
+KERNEL32W(kw_min_u32,    "v_min_u32 %0, %1, %0")
+KERNEL32W(kw_add_dpp,    "v_add_u32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+KERNEL32W(kw_pk_add_u16, "v_pk_add_u16 %0, %1, %0")
+KERNEL32W(kw_add3_u32,   "v_add3_u32 %0, %1, %2, %0")
+KERNEL32W(kw_cndmask,    "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+KERNEL32W(kw_sad_const,  "v_sad_u32 %0, %1, %2, 0")
+KERNEL32W(kw_sub_sgpr,   "v_sub_u32 %0, %0, s20")
 KERNEL64(k_qsad_pk,      "v_qsad_pk_u16_u8 %0, %1, %2, %0")
 KERNEL64(k_mqsad_pk,     "v_mqsad_pk_u16_u8 %0, %1, %2, %0")
 KERNEL64(k_lshl_b64,     "v_lshlrev_b64 %0, 1, %0")
@@ -195,12 +220,16 @@ int main() {
     {"v_add_u32_dpp row_bcast:15", k_add_dpp_bc15, 1}, {"v_mov_b32_dpp row_shr:1", k_mov_dpp_rshr1, 1},
     {"v_sub_u32_sdwa BYTE_1", k_sub_sdwa, 1}, {"v_mad_u32_u24", k_mad_u32_u24, 1}, {"v_dot4_u32_u8", k_dot4_u32_u8, 1},
     {"and_b32", k_and_b32, 1}, {"or_b32", k_or_b32, 1}, {"xor_b32", k_xor_b32, 1}, {"lshlrev_b32", k_lshlrev_b32, 1}, {"lshrrev_b32", k_lshrrev_b32, 1}, {"max_u32", k_max_u32, 1}, {"mov_b32", k_mov_b32, 1}, {"add_u16", k_add_u16, 1}, {"min_u16", k_min_u16, 1}, {"mul_u32_u24", k_mul_u32_u24, 1}, {"add_f32", k_add_f32, 1}, {"fma_f32", k_fma_f32, 1}, {"add_u32_e64", k_add_u32_e64, 1}, {"add_co_u32", k_add_co_u32, 1}, {"add_u32_sdwa", k_add_u32_sdwa, 1}, {"add_lshl", k_add_lshl, 1}, {"cmp_cnd", k_cmp_cnd, 2}, {"cnd_e64", k_cnd_e64, 1}, {"cmp_only", k_cmp_only, 2}, {"mix_add_sad", k_mix_add_sad, 2}, {"mix_add_add_sad", k_mix_add_add_sad, 3}, {"pk_lshl_b16", k_pk_lshl_b16, 1}, {"pk_max_i16", k_pk_max_i16, 1}, {"sub_u32_sgpr", k_sub_u32_sgpr, 1}, {"sad_u8_sgpr", k_sad_u8_sgpr, 1}, {"addc_u32", k_addc_u32, 1}, 
+    {"[24 chains] v_add_u32", kw_add_u32, 1}, {"[24 chains] v_sad_u32", kw_sad_u32, 1}, {"[24 chains] v_sad_u8", kw_sad_u8, 1},
+    {"[24 chains] v_min3_u32", kw_min3_u32, 1}, {"[24 chains] v_min_u32", kw_min_u32, 1}, {"[24 chains] v_add_u32_dpp wshr", kw_add_dpp, 1},
+    {"[24 chains] v_pk_add_u16", kw_pk_add_u16, 1}, {"[24 chains] v_add3_u32", kw_add3_u32, 1}, {"[24 chains] v_cndmask_e64", kw_cndmask, 1},
+    {"[24 chains] v_sad_u32 ..,0", kw_sad_const, 1}, {"[24 chains] v_sub_u32 sgpr", kw_sub_sgpr, 1},
     {"v_qsad_pk_u16_u8", k_qsad_pk, 1}, {"v_mqsad_pk_u16_u8", k_mqsad_pk, 1}, {"v_lshlrev_b64", k_lshl_b64, 1},
   };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("%-28s %12s %14s %10s\n", "instruction", "ms", "Tlane-inst/s", "cyc/wave-inst/SIMD@nominal");
   for (auto& e : es) {
-    double inst_per_lane = (double)ITER * 16.0 * e.ops_per_inst;
+    double inst_per_lane = (std::string(e.name).rfind("[24", 0) == 0 ? (double)(ITER * 16 / 24) * 24.0 : (double)ITER * 16.0) * e.ops_per_inst;
     e.fn<<<blocks, threads>>>(d, 0x01020304u, 0x0a0b0c0du);   // warm-up
     CK(hipDeviceSynchronize());
     float best = 1e30f;
