@@ -46,30 +46,21 @@ def main():
     import torch
     import steroscopic_hardware_amd as sha
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist, rank, world, local = sha.shard.init("nccl", dev)
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    dist = None
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     # parameters: rank 0 decides, everyone else receives them (2 x int32 over RCCL/xGMI)
-    params = torch.tensor([BLOCK, MAXDISP] if rank == 0 else [0, 0], dtype=torch.int32, device=dev)
-    if dist is not None:
-        dist.broadcast(params, src=0)
-    block, maxdisp = (int(v) for v in params.cpu())
+    block, maxdisp = sha.shard.broadcast_params(dist, rank, BLOCK, MAXDISP, dev)
 
     F = args.frames_per_gpu
-    seeds = [1000 + rank + world * k for k in range(F)]          # frame i -> GPU i mod G
+    seeds = sha.shard.frame_seeds(rank, world, F)                 # frame i -> GPU i mod G
     Ls, Rs = [], []
     for c in range(0, F, 16):                                     # generate in HBM, in chunks
         l, r = sha.synth.synth_batch_torch(seeds[c:c + 16], W, H, dev)
@@ -85,8 +76,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    sha.shard.barrier(dist)
     torch.cuda.synchronize(dev)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -95,14 +85,9 @@ def main():
         step()
         e1.record(stream)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    sha.shard.barrier(dist)
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sha.shard.max_over_ranks(dist, time.perf_counter() - t0, dev)
     launch_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     avg_launch_ms = sum(launch_ms) / len(launch_ms)
 
@@ -147,6 +132,16 @@ def main():
                      "kernel_avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "note": "path is integer-VALU bound (SURVEY 8d); see gcand_per_s and DESIGN.md"},
     }
+
+    # HBM traffic per launch from the committed PMC profile (only when it is this exact launch shape)
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        if (tj["frames_per_launch"], tj["width"], tj["height"], tj["block"], tj["maxdisp"]) == (F, W, H, block, maxdisp) \
+                and res["config"]["kernel_kind"] == 1:
+            res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+            res["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, round %d)" % tj["round"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     if not args.no_cpu_baseline:
         import oracle

@@ -7,11 +7,12 @@ Layout (only what the path needs):
   despair.py   Python mirror of the Go API surface (RunSad, SetupConcurrentSAD, ...) over capi
   host/        C++ mirror of the Go API + the cgo shim source a maintainer drops into pkg/despair
   synth.py     the synthetic stereo-pair generator of SURVEY.md section 8(d) (bench/test input)
+  shard.py     frame-stream sharding across ranks + the parameter broadcast (multi-GPU)
 
 The product path has no CPU fallback: importing ``capi`` without a built libsadhip.so, or
 calling it without a GPU, fails loudly.
 """
-from . import capi, despair, synth  # noqa: F401
+from . import capi, despair, shard, synth  # noqa: F401
 from .capi import SadHipError, Context, build_library  # noqa: F401
 
-__all__ = ["capi", "despair", "synth", "SadHipError", "Context", "build_library"]
+__all__ = ["capi", "despair", "shard", "synth", "SadHipError", "Context", "build_library"]

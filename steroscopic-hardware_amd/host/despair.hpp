@@ -1,0 +1,90 @@
+// despair.hpp -- C++ mirror of the Go API of pkg/despair (the reference's compiled host side),
+// implemented over the C ABI of libsadhip.so (include/sadhip.h).  Same names, argument meaning
+// and ownership rules as the reference so callers (pkg/camera/output.go, examples/run*.go) map
+// one to one; the cgo shim in go/ is the same logic in Go.
+//
+//   Go (pkg/despair)                                   here
+//   type Parameters{BlockSize,MaxDisparity}            despair::Parameters            params.go:32-37
+//   SetDefaultParams / DefaultParams                   despair::SetDefaultParams/...  params.go:21-30
+//   type InputChunk / OutputChunk                      despair::InputChunk/OutputChunk sad.go:11-21
+//   SetupConcurrentSAD(numWorkers)                     despair::SetupConcurrentSAD    sad.go:29-113
+//   AssembleDisparityMap(out, dims, chunks)            despair::AssembleDisparityMap  sad.go:172-202
+//   RunSad(left, right, blockSize, maxDisparity)       despair::RunSad                sad.go:119-169
+//   SumAbsoluteDifferences(...)                        despair::SumAbsoluteDifferences sad.go:205-244
+//
+// Deliberate differences: AssembleDisparityMap writes every chunk (the
+// reference drops the last one, sad.go:181-184); errors are exceptions carrying the C-ABI status
+// instead of panics; there is no CPU fallback.
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace despair {
+
+struct Rectangle { int x0 = 0, y0 = 0, x1 = 0, y1 = 0; int Dx() const { return x1 - x0; } int Dy() const { return y1 - y0; } };
+
+// image.Gray with Rect.Min == (0,0): Pix[y*Stride + x]
+struct Gray {
+  std::vector<uint8_t> Pix; int Stride = 0; Rectangle Rect;
+  Gray() = default;
+  explicit Gray(Rectangle r) : Pix((size_t)r.Dx() * r.Dy()), Stride(r.Dx()), Rect(r) {}
+  Gray(int w, int h) : Gray(Rectangle{0, 0, w, h}) {}
+};
+
+struct Parameters { int BlockSize = 16; int MaxDisparity = 64; };
+void SetDefaultParams(Parameters p);
+Parameters DefaultParams();
+
+struct InputChunk { std::shared_ptr<const Gray> Left, Right; Rectangle Region; };
+struct OutputChunk { std::vector<uint8_t> DisparityData; Rectangle Region; };
+
+class Error : public std::runtime_error {
+ public:
+  Error(int status, const std::string& what) : std::runtime_error(what), status(status) {}
+  int status;
+};
+
+// Buffered channel with Go semantics: send blocks when full, recv returns false once closed and drained.
+template <typename T>
+class Chan {
+ public:
+  explicit Chan(size_t cap) : cap_(cap ? cap : 1) {}
+  void send(T v) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_send_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+    if (closed_) throw std::logic_error("send on closed channel");
+    q_.push_back(std::move(v));
+    cv_recv_.notify_one();
+  }
+  bool recv(T& out) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_recv_.wait(lk, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return false;
+    out = std::move(q_.front());
+    q_.pop_front();
+    cv_send_.notify_one();
+    return true;
+  }
+  void close() { std::lock_guard<std::mutex> lk(mu_); closed_ = true; cv_recv_.notify_all(); cv_send_.notify_all(); }
+ private:
+  std::mutex mu_; std::condition_variable cv_send_, cv_recv_; std::deque<T> q_; size_t cap_; bool closed_ = false;
+};
+
+struct Pipeline { std::shared_ptr<Chan<InputChunk>> in; std::shared_ptr<Chan<OutputChunk>> out; };
+
+// sad.go:29-113.  One device worker replaces the goroutine pool; closing `in` stops it and closes `out`.
+Pipeline SetupConcurrentSAD(int numWorkers, int device = 0);
+// sad.go:172-202 (hole-free).
+Gray AssembleDisparityMap(Chan<OutputChunk>& out, Rectangle dimensions, int chunks);
+// sad.go:119-169: sets the global parameters, one frame-level device call.
+Gray RunSad(const Gray& left, const Gray& right, int blockSize, int maxDisparity, int device = 0);
+// sad.go:205-244.
+int SumAbsoluteDifferences(const Gray& left, const Gray& right, int leftX, int leftY, int rightX, int rightY, int blockSize);
+
+}  // namespace despair

@@ -20,3 +20,8 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   echo "pmc [$grp] exit=$?"
 done
 find $OUT -name "*.csv" | head -40
+# calibration of FETCH_SIZE / WRITE_SIZE on known byte counts in the kernel's access shapes
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_calib_$c -o pmc -- $ROOT/tools/ubench/hbm_calib > $OUT/calib_$c.log 2>&1
+  echo "calib [$c] exit=$?"
+done
