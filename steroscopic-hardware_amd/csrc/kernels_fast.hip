@@ -231,33 +231,32 @@ struct Cw {                                         // P columns per lane: 4 (h 
     for (int i = tid; i <= j.maxdisp; i += nt)
       lut[i] = (unsigned char)(j.raw ? min(i, 255) : (i * 255) / j.maxdisp);     // sad.go:91-93
 
-    // ---- ring loader.  A ring row holds L columns [tx, tx+TW) then R columns [tx-dpad, tx+TW),
-    //      as u32 pixels shifted by ksh, zero outside the image.  Element i of a row is fetched by
-    //      thread i % nt in prefetch slot i / nt.  Everything that does not depend on the row is
-    //      hoisted here: clamped column, validity mask, and whether the slot reads L or R (uniform
-    //      per wave because TW is a multiple of 64), so the loop issues bare scalar-base loads.
-    constexpr int MAXV = 3;                               // register-prefetched values per thread
+    // ---- ring rows: L columns [tx, tx+TW) then R columns [tx-dpad, tx+TW), u32 pixels shifted by
+    //      ksh, zero outside the image.
     const int nvals = ROWW;
-    int pcol[MAXV];                                       // clamped image column
-    unsigned pmask[MAXV];                                 // 0xff when the column exists, else 0
-    bool pisR[MAXV];
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int i = tid + v * nt;
-      pisR[v] = (wv * 64 + v * nt) >= TW;                 // wave-uniform
-      const int col = pisR[v] ? tx - a.dpad + (i - TW) : tx + i;
-      pmask[v] = (i < nvals && col >= 0 && col < j.w) ? 0xffu : 0u;
-      pcol[v] = min(max(col, 0), j.w - 1);
-    }
-    auto fetch = [&](int yy, int i) -> unsigned {         // generic element fetch (setup / tiny workgroups)
+    auto fetch = [&](int yy, int i) -> unsigned {         // element i of the ring row of image row yy
       const bool isR = i >= TW;
       const int col = isR ? tx - a.dpad + (i - TW) : tx + i;
       if (yy < 0 || yy >= j.h || col < 0 || col >= j.w) return 0u;
       const uint8_t* base = isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride;
       return (unsigned)base[col];
     };
+    {                                                     // first window row resident before the loop
+      unsigned* dst = ring;                               // row ys-H lives in slot 0
+      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(ys - H, i) << a.ksh;
+    }
+    __syncthreads();
 
-    // ---- per-lane state ----------------------------------------------------------------------
+    const int nsteps = (ye - ys) + 2 * H;                 // ring slots advance by one per step
+    // Roles: waves [0, nw) compute; wave nw is the helper that streams rows into the ring and
+    // turns finished row buffers into output, so the compute waves' loop is VALU + LDS reads only.
+    // Every wave executes exactly one barrier per step.
+    if (wv == a.nw) {
+      helper_loop(a, ring, rowbest, lut, Lg, Rg, Og, ROWW, nvals, tx, ys, nsteps, ox0, ox1, lane);
+      return;
+    }
+
+    // ---- per-lane state of a compute wave ------------------------------------------------------
     const int x0 = tx + P * lane;                         // first column of this lane
     const bool lane_valid = x0 < j.w;                     // (w - tx) % P == 0: all-or-nothing
     unsigned C[P][ND];
@@ -277,38 +276,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int lofs = P * lane;
     const int rofs = TW + (a.dpad - dc - (ND - 1)) + P * lane;        // multiple of 4 by construction
 
-    {                                                     // first window row resident before the loop
-      unsigned* dst = ring;                               // row ys-H lives in slot 0
-      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(ys - H, i) << a.ksh;
-    }
-    __syncthreads();
-
-    // ring slots advance by one per step: row ys-H+t lives in slot t % NR
-    int slot_in = 0;                                      // slot of the entering row
-    const int nsteps = (ye - ys) + 2 * H;
+    int slot_in = 0;                                      // row ys-H+t lives in slot t % NR
     for (int t = 0; t < nsteps; ++t) {
-      const int yin = ys - H + t;                         // row entering the window
-      const int y = yin - H;                              // output row of this step (t >= 2H)
-      const bool have_next = t + 1 < nsteps;
-      const int slot_next = slot_in + 1 == NR ? 0 : slot_in + 1;
-      // the leaving row yin-B1 sits NR-B1 = 2 slots ahead; before the window is full: the zero row
+      // the leaving row sits NR-B1 = 2 slots ahead; before the window is full: the zero row
       const int slot_out = t > 2 * H ? (slot_in + 2 >= NR ? slot_in + 2 - NR : slot_in + 2) : NR;
-
-      // prefetch the next entering row into registers (raw bytes; landed at the end of the step)
-      unsigned pf[MAXV];
-      const int yn = yin + 1;
-      const bool row_ok = have_next && yn >= 0 && yn < j.h && !(a.dbg & 8);       // uniform
-      if (row_ok) {
-        const uint8_t* lrow = Lg + (size_t)(yn - j.row0) * j.lstride;
-        const uint8_t* rrow = Rg + (size_t)(yn - j.row0) * j.rstride;
-#pragma unroll
-        for (int v = 0; v < MAXV; ++v) pf[v] = (pisR[v] ? rrow : lrow)[pcol[v]];
-      } else {
-#pragma unroll
-        for (int v = 0; v < MAXV; ++v) pf[v] = 0u;
-      }
-
-      // vertical update of the column sums
       const unsigned* rin = ring + slot_in * ROWW;
       const unsigned* rout = ring + slot_out * ROWW;
       if (lane_valid && !(a.dbg & 1))
@@ -330,30 +301,85 @@ struct Cw {                                         // P columns per lane: 4 (h 
 #pragma unroll
         for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]);          // ds_min_u32
       }
+      __syncthreads();
+      slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
+    }
+    __syncthreads();                                      // pairs with the helper's final barrier
+  }
 
-      // land the prefetched row (its slot held row yout-1, last read in the previous step)
+  // ---- helper wave: row streaming + output --------------------------------------------------------
+  // Step t (between barrier t-1 and barrier t): issue the global loads of row ys-H+t+2 (two rows
+  // ahead, so their latency spans a whole step), finalize the output row of step t-1 from its
+  // (now complete) row buffer and reset it, then land row ys-H+t+1 (loaded during step t-1) in the
+  // ring slot that held the row which left the window two steps ago.
+  static __device__ __forceinline__ void helper_loop(const CwArgs& a, unsigned* ring, unsigned* rowbest,
+                                                  const unsigned char* lut,
+                                                  const uint8_t* __restrict__ Lg, const uint8_t* __restrict__ Rg,
+                                                  uint8_t* __restrict__ Og, int ROWW, int nvals, int tx, int ys,
+                                                  int nsteps, int ox0, int ox1, int lane)
+  {
+    const Job& j = a.j;
+    constexpr int MAXV = (2 * TW + 16 * 12 + 63) / 64;   // ring-row elements per helper lane (worst case)
+    int pcol[MAXV];                                       // image column, or -1: always zero
+    const int nL = TW;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int i = lane + 64 * v;
+      const int col = i >= nL ? tx - a.dpad + (i - nL) : tx + i;
+      pcol[v] = (i < nvals && col >= 0 && col < j.w) ? col : -1;
+    }
+    auto load_row = [&](int yy, unsigned (&pf)[MAXV]) {   // raw bytes of image row yy (0 outside the image)
+      if (yy >= 0 && yy < j.h && !(a.dbg & 8)) {
+        const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * j.lstride;
+        const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * j.rstride;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v)                    // slots below TW/64 read L, the rest R (compile time)
+          pf[v] = pcol[v] >= 0 ? (unsigned)(64 * v >= nL ? rrow : lrow)[pcol[v]] : 0u;
+      } else {
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) pf[v] = 0u;
+      }
+    };
+    const unsigned kmask = (1u << a.ksh) - 1u;
+    auto finalize = [&](int t) {                          // output row of step t: 4 pixels per lane per pass
+      const int y = ys + t - 2 * H;
+      uint4* rb = reinterpret_cast<uint4*>(rowbest + (t & 1) * TW);
+      uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride - j.ox;
+#pragma unroll
+      for (int g = 0; g < TW / 256; ++g) {
+        const int i = 4 * (lane + 64 * g);
+        const uint4 k = rb[lane + 64 * g];
+        rb[lane + 64 * g] = make_uint4(KEY_INVALID, KEY_INVALID, KEY_INVALID, KEY_INVALID);
+        const unsigned char v0 = lut[k.x & kmask], v1 = lut[k.y & kmask], v2 = lut[k.z & kmask], v3 = lut[k.w & kmask];
+        const int x = tx + i;
+        if (x >= ox0 && x < ox1) orow[x] = v0;
+        if (x + 1 >= ox0 && x + 1 < ox1) orow[x + 1] = v1;
+        if (x + 2 >= ox0 && x + 2 < ox1) orow[x + 2] = v2;
+        if (x + 3 >= ox0 && x + 3 < ox1) orow[x + 3] = v3;
+      }
+    };
+    unsigned pfa[MAXV], pfb[MAXV];
+    load_row(ys - H + 1, pfa);                            // row that step 0 lands
+    int slot_next = 1 == NR ? 0 : 1;
+    for (int t = 0; t < nsteps; ++t) {
+      const bool have_next = t + 1 < nsteps;
+      if (t + 2 < nsteps) load_row(ys - H + t + 2, pfb);  // two rows ahead
+      if (t > 2 * H && !(a.dbg & 4)) finalize(t - 1);
       if (have_next) {
         unsigned* dst = ring + slot_next * ROWW;
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
-          const int i = tid + v * nt;
-          if (i < nvals) dst[i] = (pf[v] & pmask[v]) << a.ksh;
-        }
-        for (int i = tid + MAXV * nt; i < nvals; i += nt) dst[i] = fetch(yn, i) << a.ksh;   // tiny workgroups
-      }
-      if (!(a.dbg & 16)) __syncthreads();
-
-      if (t >= 2 * H && !(a.dbg & 4)) {                   // key -> d -> u8, reset the row buffer
-        unsigned* rb = rowbest + (t & 1) * TW;
-        uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride - j.ox;
-        for (int x = ox0 + tid; x < ox1; x += nt) {
-          const unsigned key = rb[x - tx];
-          rb[x - tx] = KEY_INVALID;
-          orow[x] = lut[key & ((1u << a.ksh) - 1u)];
+          const int i = lane + 64 * v;
+          if (i < nvals) dst[i] = pfa[v] << a.ksh;
         }
       }
-      slot_in = slot_next;
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) pfa[v] = pfb[v];
+      slot_next = slot_next + 1 == NR ? 0 : slot_next + 1;
     }
+    if (!(a.dbg & 4)) finalize(nsteps - 1);
+    __syncthreads();
   }
 };
 
@@ -370,7 +396,7 @@ Plan plan_for(int maxdisp, int p)
   Plan best{0, 0};
   int best_waste = 1 << 30;
   const int nds[] = {12, 8};
-  const int max_waves = p == 4 ? 16 : 12;
+  const int max_waves = p == 4 ? 15 : 11;                       // + 1 helper wave per workgroup
   const char* force = getenv("SADHIP_TUNE_ND");                 // tuning aid: force a chunk size
   for (int nd : nds) {
     if (force && atoi(force) != nd) continue;
@@ -403,9 +429,11 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   const int ntiles = k1 - k0 + 1;
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
-  // strip height: enough workgroups to fill 256 CUs a few times over, else as tall as possible
+  // strip height.  512 workgroups (2 per CU) are resident at once; a launch runs fastest when its
+  // workgroup count is about a multiple of that (no ragged last round) and strips are tall (each
+  // strip repeats 2h warm-up rows): split rows only until one full round exists.
   const char* want_env = getenv("SADHIP_TUNE_WGS");           // tuning aid: target workgroup count
-  const long want = want_env ? atol(want_env) : 2048;
+  const long want = want_env ? atol(want_env) : 512;
   long nstrips = (want + (long)ntiles * j.n - 1) / ((long)ntiles * j.n);
   const long max_strips = (rows + 15) / 16;
   if (nstrips > max_strips) nstrips = max_strips;
@@ -420,7 +448,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
     aa.j.left += (size_t)f0 * j.left_frame_stride;
     aa.j.right += (size_t)f0 * j.right_frame_stride;
     aa.j.out += (size_t)f0 * j.out_frame_stride;
-    hipLaunchKernelGGL((k_colwave<P, ND, H>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * (pl.nw + 1)), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
