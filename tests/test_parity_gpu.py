@@ -86,6 +86,34 @@ def test_edge_shapes(ctx, w, h, block, maxdisp, flags):
                           np.minimum(_expect(L, R, block, maxdisp, raw=True), 255))
 
 
+def test_random_parameter_sweep(ctx):
+    """60 seeded random (w, h, BlockSize, MaxDisparity) draws over the ranges the WebUI allows and
+    beyond (cmd/handlers/params.go:37-52: block 3..31 odd, maxDisp 16..256 step 16), every kernel
+    variant the dispatcher can pick, against the oracle."""
+    rng = np.random.default_rng(2024)
+    kinds = set()
+    for i in range(60):
+        w = int(rng.integers(1, 700)); h = int(rng.integers(1, 60))
+        block = int(rng.integers(1, 33)); maxdisp = int(rng.choice([1, 5, 16, 32, 48, 64, 80, 96, 128, 144, 192, 256]))
+        L, R = sha.synth.synth_pair(5000 + i, w, h)
+        if i % 7 == 0:
+            R = L.copy()                                      # exact matches: SAD 0, ties everywhere
+        kinds.add((capi.kernel_kind(w, h, block, maxdisp), block // 2 > 4))
+        got = ctx.disparity(L, R, block, maxdisp, capi.FLAG_RAW)
+        assert np.array_equal(got, np.minimum(_expect(L, R, block, maxdisp, raw=True), 255)), (w, h, block, maxdisp)
+    assert (1, False) in kinds and (1, True) in kinds and (0, True) in kinds    # P=4, P=8 and generic all exercised
+
+
+def test_tall_frame_many_strips_and_tiles(ctx):
+    """Strip seams (2h warm-up rows) and tile seams (halo lanes) on a frame taller/wider than any tile."""
+    L, R = sha.synth.synth_pair(77, 1100, 700)
+    for block, maxdisp in ((9, 64), (5, 16), (13, 48)):
+        got = ctx.disparity(L, R, block, maxdisp)
+        for reg in ((0, 0, 1100, 3), (0, 697, 1100, 700), (240, 300, 270, 330), (490, 100, 530, 110), (1080, 0, 1100, 700)):
+            assert np.array_equal(got[reg[1]:reg[3], reg[0]:reg[2]], oracle.disparity_closed(L, R, block, maxdisp, region=reg)), (block, maxdisp, reg)
+        assert np.array_equal(got, ctx.disparity(L, R, block, maxdisp, capi.FLAG_FORCE_GENERIC))
+
+
 @pytest.mark.parametrize("flags", BOTH)
 def test_flat_images_tie_to_zero(ctx, flags):
     L = np.full((90, 300), 200, np.uint8)
