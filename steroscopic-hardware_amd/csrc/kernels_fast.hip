@@ -36,7 +36,8 @@ namespace {
 struct CwArgs {
   Job j;
   int nw;          // waves per workgroup (disparity chunks)
-  int ksh;         // key shift: 2^ksh > maxdisp
+  int ksh;         // bits of the disparity field of a key (unpacked: 2^ksh > maxdisp; packed: 16)
+  int pixshift;    // left shift applied to pixels landing in LDS (unpacked: ksh; packed: 0)
   int dpad;        // columns of R kept left of the tile: nw*ND - 1 (== 3 mod 4)
   int tx0;         // origin of tile 0 (<= 0, == w mod P)
   int tile0;       // first tile index launched (blockIdx.x + tile0)
@@ -71,6 +72,31 @@ __device__ __forceinline__ void sad_sub4(unsigned& c0, unsigned& c1, unsigned& c
       : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
       : "v"(l), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
 }
+// ---- packed variant: one register holds the column sums of two adjacent disparities as u16 halves.
+// Pixels in LDS are plain zero-extended bytes, so v_sad_u8 / v_sad_hi_u8 (|a-b| over 4 byte lanes,
+// result added to the low / high half of the accumulator) are exact single-pixel differences.
+// Two registers (four candidates) per asm statement, independent chains interleaved.
+__device__ __forceinline__ void pk_sad_in2(unsigned& c0, unsigned& c1, unsigned l,
+                                           unsigned re0, unsigned ro0, unsigned re1, unsigned ro1)
+{
+  asm("v_sad_u8 %0, %2, %3, %0\n\t"
+      "v_sad_u8 %1, %2, %5, %1\n\t"
+      "v_sad_hi_u8 %0, %2, %4, %0\n\t"
+      "v_sad_hi_u8 %1, %2, %6, %1"
+      : "+v"(c0), "+v"(c1) : "v"(l), "v"(re0), "v"(ro0), "v"(re1), "v"(ro1));
+}
+__device__ __forceinline__ void pk_sad_out2(unsigned& c0, unsigned& c1, unsigned l,
+                                            unsigned re0, unsigned ro0, unsigned re1, unsigned ro1)
+{
+  unsigned t0, t1;
+  asm("v_sad_u8 %2, %4, %5, 0\n\t"
+      "v_sad_u8 %3, %4, %7, 0\n\t"
+      "v_sad_hi_u8 %2, %4, %6, %2\n\t"
+      "v_sad_hi_u8 %3, %4, %8, %3\n\t"
+      "v_sub_u32 %0, %0, %2\n\t"
+      "v_sub_u32 %1, %1, %3"
+      : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1) : "v"(l), "v"(re0), "v"(ro0), "v"(re1), "v"(ro1));
+}
 __device__ __forceinline__ unsigned from_left(unsigned v)     // lane l <- lane l-1 (lane 0: 0)
 {
 #if defined(SADHIP_EXP) && SADHIP_EXP == 1
@@ -90,8 +116,11 @@ __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane 
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
 }
 
-template <int P, int ND, int H>
+template <int P, int ND, int H, bool PK>
 struct Cw {                                         // P columns per lane: 4 (h <= 4) or 8 (h <= 8)
+  // PK: column sums of disparity pairs packed as u16 halves (window SAD < 65536, i.e. h <= 7)
+  static_assert(!PK || (H <= 7 && ND % 4 == 0), "packed sums need (2h+1)^2 * 255 < 65536");
+  static constexpr int NC = PK ? ND / 2 : ND;       // accumulator registers per column
   static_assert(P == 4 || P == 8, "operand reads are whole ds_read_b128");
   static_assert(H >= 1 && H <= P, "halo must fit in the neighbour lane");
   static_assert(ND % 4 == 0, "ND must keep every lane's R operands 16-byte aligned");
@@ -104,7 +133,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
 
   // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
   // lin/lout: this lane's 4 L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
-  static __device__ __forceinline__ void update_columns(unsigned (&C)[P][ND],
+  static __device__ __forceinline__ void update_columns(unsigned (&C)[P][NC],
                                                         const uint4* lin, const uint4* rin,
                                                         const uint4* lout, const uint4* rout)
   {
@@ -120,10 +149,19 @@ struct Cw {                                         // P columns per lane: 4 (h 
         const uint4 r4 = rin[m];
         ri[4 * m] = r4.x; ri[4 * m + 1] = r4.y; ri[4 * m + 2] = r4.z; ri[4 * m + 3] = r4.w;
       }
+      if constexpr (PK) {
 #pragma unroll
-      for (int p = 0; p < P; ++p)
+        for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int q = 0; q < ND; ++q) sad_acc(C[p][q], li[p], ri[p + ND - 1 - q]);
+          for (int r = 0; r < NC; r += 2)                   // candidates q = 2r .. 2r+3
+            pk_sad_in2(C[p][r], C[p][r + 1], li[p], ri[p + ND - 1 - 2 * r], ri[p + ND - 2 - 2 * r],
+                       ri[p + ND - 3 - 2 * r], ri[p + ND - 4 - 2 * r]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+          for (int q = 0; q < ND; ++q) sad_acc(C[p][q], li[p], ri[p + ND - 1 - q]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);                    // keep the two operand sets from overlapping
     {
@@ -138,12 +176,21 @@ struct Cw {                                         // P columns per lane: 4 (h 
         const uint4 r4 = rout[m];
         ro[4 * m] = r4.x; ro[4 * m + 1] = r4.y; ro[4 * m + 2] = r4.z; ro[4 * m + 3] = r4.w;
       }
+      if constexpr (PK) {
 #pragma unroll
-      for (int p = 0; p < P; ++p)
+        for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int q = 0; q < ND; q += 4)
-          sad_sub4(C[p][q], C[p][q + 1], C[p][q + 2], C[p][q + 3], lo[p], ro[p + ND - 1 - q],
-                   ro[p + ND - 2 - q], ro[p + ND - 3 - q], ro[p + ND - 4 - q]);
+          for (int r = 0; r < NC; r += 2)
+            pk_sad_out2(C[p][r], C[p][r + 1], lo[p], ro[p + ND - 1 - 2 * r], ro[p + ND - 2 - 2 * r],
+                        ro[p + ND - 3 - 2 * r], ro[p + ND - 4 - 2 * r]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+          for (int q = 0; q < ND; q += 4)
+            sad_sub4(C[p][q], C[p][q + 1], C[p][q + 2], C[p][q + 3], lo[p], ro[p + ND - 1 - q],
+                     ro[p + ND - 2 - q], ro[p + ND - 3 - q], ro[p + ND - 4 - q]);
+      }
     }
   }
 
@@ -155,7 +202,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // A(q+1) is issued between A(q) and B(q), pinned with sched_barrier.
   struct Pre { unsigned ps[P + 1]; unsigned suf[P + 1]; };   // suf[k] = sum of the lane's last k columns
 
-  static __device__ __forceinline__ void stage_a(const unsigned (&C)[P][ND], int q, Pre& r)
+  static __device__ __forceinline__ void stage_a(const unsigned (&C)[P][NC], int q, Pre& r)
   {
     r.ps[0] = 0;
 #pragma unroll
@@ -164,8 +211,11 @@ struct Cw {                                         // P columns per lane: 4 (h 
     for (int k = 1; k <= H && k <= P; ++k) r.suf[k] = r.ps[P] - r.ps[P - k];
   }
 
+  // Unpacked: the window sum is the key (bias trick).  Packed: the window sums of disparities
+  // dbase+2q (low half) and dbase+2q+1 (high half) become two keys (SAD << 16) | d.
   template <bool MASK>
-  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const int (&jlim)[P], unsigned (&best)[P])
+  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const int (&jlim)[P], unsigned (&best)[P],
+                                                 unsigned dbase)
   {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -175,22 +225,33 @@ struct Cw {                                         // P columns per lane: 4 (h 
       if (a < 0) s += from_left(r.suf[-a]);                // last (-a) columns of the left lane
       if (a < 0 && b > P - 1) asm("" : "+v"(s));           // two v_add_u32_dpp, not v_mov_dpp x2 + v_add3
       if (b > P - 1) s += from_right(r.ps[b - P + 1]);     // first (b-P+1) columns of the right lane
-      if (MASK) s = (q > jlim[p]) ? KEY_INVALID : s;       // d > min(D, x-h): not a candidate
-      best[p] = s < best[p] ? s : best[p];
+      if constexpr (PK) {
+        unsigned ke = (s << 16) | (dbase + 2 * q);           // v_lshl_or_b32
+        unsigned ko = (s & 0xffff0000u) | (dbase + 2 * q + 1); // v_and_or_b32
+        if (MASK) {
+          ke = (2 * q > jlim[p]) ? KEY_INVALID : ke;
+          ko = (2 * q + 1 > jlim[p]) ? KEY_INVALID : ko;
+        }
+        const unsigned m = ke < ko ? ke : ko;
+        best[p] = m < best[p] ? m : best[p];                 // v_min3_u32
+      } else {
+        if (MASK) s = (q > jlim[p]) ? KEY_INVALID : s;       // d > min(D, x-h): not a candidate
+        best[p] = s < best[p] ? s : best[p];
+      }
     }
   }
 
   template <bool MASK>
-  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][ND], const int (&jlim)[P],
-                                                    unsigned (&best)[P])
+  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][NC], const int (&jlim)[P],
+                                                    unsigned (&best)[P], unsigned dbase)
   {
     Pre cur, nxt;
     stage_a(C, 0, cur);
 #pragma unroll
-    for (int q = 0; q < ND; ++q) {
-      if (q + 1 < ND) stage_a(C, q + 1, nxt);
+    for (int q = 0; q < NC; ++q) {
+      if (q + 1 < NC) stage_a(C, q + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
-      stage_b<MASK>(cur, q, jlim, best);
+      stage_b<MASK>(cur, q, jlim, best, dbase);
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
     }
@@ -243,7 +304,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
     };
     {                                                     // first window row resident before the loop
       unsigned* dst = ring;                               // row ys-H lives in slot 0
-      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(ys - H, i) << a.ksh;
+      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(ys - H, i) << a.pixshift;
     }
     __syncthreads();
 
@@ -259,15 +320,15 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // ---- per-lane state of a compute wave ------------------------------------------------------
     const int x0 = tx + P * lane;                         // first column of this lane
     const bool lane_valid = x0 < j.w;                     // (w - tx) % P == 0: all-or-nothing
-    unsigned C[P][ND];
+    unsigned C[P][NC];
     int jlim[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int col = x0 + p;
-      const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
+      const bool biased = !PK && ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
       jlim[p] = min(j.maxdisp, max(0, col - H)) - dc;     // candidate q valid iff q <= jlim[p]
 #pragma unroll
-      for (int q = 0; q < ND; ++q) C[p][q] = biased ? (unsigned)(dc + q) : 0u;
+      for (int q = 0; q < NC; ++q) C[p][q] = biased ? (unsigned)(dc + q) : 0u;
     }
     // is any (pixel, d) of this wave outside the candidate range?  (wave-uniform)
     const bool need_mask = (dc + ND - 1 > j.maxdisp) || (max(ox0, 0) - H < dc + ND - 1);
@@ -293,15 +354,15 @@ struct Cw {                                         // P columns per lane: 4 (h 
         if (need_mask) {
 #pragma unroll
           for (int p = 0; p < P; ++p) asm volatile("" : "+v"(jlim[p]));   // keep the compares in the loop
-          reduce_row<true>(C, jlim, best);
+          reduce_row<true>(C, jlim, best, (unsigned)dc);
         } else {
-          reduce_row<false>(C, jlim, best);
+          reduce_row<false>(C, jlim, best, (unsigned)dc);
         }
         unsigned* rb = rowbest + (t & 1) * TW + lofs;
 #pragma unroll
         for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]);          // ds_min_u32
       }
-      __syncthreads();
+      if (!(a.dbg & 16)) __syncthreads();
       slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
     }
     __syncthreads();                                      // pairs with the helper's final barrier
@@ -319,7 +380,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
                                                   int nsteps, int ox0, int ox1, int lane)
   {
     const Job& j = a.j;
-    constexpr int MAXV = (2 * TW + 16 * 12 + 63) / 64;   // ring-row elements per helper lane (worst case)
+    constexpr int MAXV = (2 * TW + 15 * ND + 63) / 64;   // ring-row elements per helper lane (15 waves worst case)
     int pcol[MAXV];                                       // image column, or -1: always zero
     const int nL = TW;
 #pragma unroll
@@ -370,10 +431,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
           const int i = lane + 64 * v;
-          if (i < nvals) dst[i] = pfa[v] << a.ksh;
+          if (i < nvals) dst[i] = pfa[v] << a.pixshift;
         }
       }
-      __syncthreads();
+      if (!(a.dbg & 16)) __syncthreads();
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) pfa[v] = pfb[v];
       slot_next = slot_next + 1 == NR ? 0 : slot_next + 1;
@@ -383,41 +444,56 @@ struct Cw {                                         // P columns per lane: 4 (h 
   }
 };
 
-// P = 4: up to 16 waves (128 VGPRs); P = 8 keeps twice the column sums: up to 12 waves (168 VGPRs)
-template <int P, int ND, int H>
-__global__ void __launch_bounds__(P == 4 ? 1024 : 768) k_colwave(CwArgs a) { Cw<P, ND, H>::run(a); }
+// 1024-thread bound = 128 VGPRs; the unpacked P = 8 kernel keeps 96 column sums: 768 threads (168 VGPRs)
+template <int P, int ND, int H, bool PK>
+__global__ void __launch_bounds__((PK || P == 4) ? 1024 : 768) k_colwave(CwArgs a) { Cw<P, ND, H, PK>::run(a); }
 
-struct Plan { int nd, nw; };
+struct Plan { int p, nd, nw; bool pk; };
 
-// chunk size / wave count covering D+1 candidates with the least idle slots (ties: ND = 12)
-Plan plan_for(int maxdisp, int p)
+int env_int(const char* name, int dflt)
 {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// Kernel variant for (h, D): columns per lane P, packed or not, chunk size ND and wave count NW
+// covering the D+1 candidates with the fewest idle slots (ties: fewer waves).
+//   packed   (h <= 7): P = 4 (h <= 4) with ND in {24, 12, 8}, or P = 8 with ND = 12; up to 15 waves
+//   unpacked (h == 8, or SADHIP_TUNE_PK=0): P = 4 ND {12, 8} up to 15 waves; P = 8 ND 12 up to 11 waves
+Plan plan_for(int h, int maxdisp)
+{
+  Plan best{0, 0, 0, false};
+  if (h < 1 || h > 8 || maxdisp < 1) return best;
+  const bool pk = h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0;
+  int p = h <= 4 ? 4 : 8;
+  const int fp = env_int("SADHIP_TUNE_P", 0);                   // tuning aid: force 4 or 8
+  if ((fp == 4 || fp == 8) && h <= fp) p = fp;
+  const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aid: force a chunk size
   const int cands = maxdisp + 1;
-  Plan best{0, 0};
+  const int max_waves = (pk || p == 4) ? 15 : 11;               // + 1 helper wave per workgroup
   int best_waste = 1 << 30;
-  const int nds[] = {12, 8};
-  const int max_waves = p == 4 ? 15 : 11;                       // + 1 helper wave per workgroup
-  const char* force = getenv("SADHIP_TUNE_ND");                 // tuning aid: force a chunk size
-  for (int nd : nds) {
-    if (force && atoi(force) != nd) continue;
-    if (p == 8 && nd != 12) continue;
+  for (int nd : {24, 12, 8}) {
+    if (force_nd && force_nd != nd) continue;
+    if (nd == 24 && !(pk && p == 4)) continue;
+    if (nd == 8 && p == 8) continue;
     const int nw = (cands + nd - 1) / nd;
     if (nw > max_waves) continue;
     const int waste = nw * nd - cands;
-    if (waste < best_waste || (waste == best_waste && nd == 12)) { best_waste = waste; best = Plan{nd, nw}; }
+    if (waste < best_waste) { best_waste = waste; best = Plan{p, nd, nw, pk}; }
   }
   return best;
 }
 
-template <int P, int ND, int H>
+template <int P, int ND, int H, bool PK>
 hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
 {
-  using K = Cw<P, ND, H>;
+  using K = Cw<P, ND, H, PK>;
   CwArgs a{};
   a.j = j;
   a.nw = pl.nw;
-  a.ksh = 32 - __builtin_clz((unsigned)j.maxdisp);            // 2^ksh > maxdisp
-  { const char* e = getenv("SADHIP_TUNE_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.ksh = PK ? 16 : 32 - __builtin_clz((unsigned)j.maxdisp);  // unpacked: 2^ksh > maxdisp
+  a.pixshift = PK ? 0 : a.ksh;
+  a.dbg = env_int("SADHIP_TUNE_DBG", 0);
   a.dpad = pl.nw * ND - 1;                                    // == 3 (mod 4): lane operands 16-B aligned
   const int r = j.w % P;
   a.tx0 = r == 0 ? 0 : r - P;
@@ -429,11 +505,9 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   const int ntiles = k1 - k0 + 1;
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
-  // strip height.  512 workgroups (2 per CU) are resident at once; a launch runs fastest when its
-  // workgroup count is about a multiple of that (no ragged last round) and strips are tall (each
-  // strip repeats 2h warm-up rows): split rows only until one full round exists.
-  const char* want_env = getenv("SADHIP_TUNE_WGS");           // tuning aid: target workgroup count
-  const long want = want_env ? atol(want_env) : 512;
+  // strip height.  About 512 workgroups are resident at once; a launch runs fastest when strips
+  // are tall (each strip repeats 2h warm-up rows): split rows only until one full round exists.
+  const long want = env_int("SADHIP_TUNE_WGS", 512);          // tuning aid: target workgroup count
   long nstrips = (want + (long)ntiles * j.n - 1) / ((long)ntiles * j.n);
   const long max_strips = (rows + 15) / 16;
   if (nstrips > max_strips) nstrips = max_strips;
@@ -448,43 +522,38 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
     aa.j.left += (size_t)f0 * j.left_frame_stride;
     aa.j.right += (size_t)f0 * j.right_frame_stride;
     aa.j.out += (size_t)f0 * j.out_frame_stride;
-    hipLaunchKernelGGL((k_colwave<P, ND, H>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * (pl.nw + 1)), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * (pl.nw + 1)), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
 
-int cols_per_lane(int h)
-{
-  const char* force = getenv("SADHIP_TUNE_P");                  // tuning aid: force 4 or 8
-  if (force && (atoi(force) == 4 || atoi(force) == 8) && h <= atoi(force)) return atoi(force);
-  return h <= 4 ? 4 : 8;
-}
-
 }  // namespace
 
 bool fast_supported(const Job& j)
 {
-  const int h = j.block / 2;
-  if (h < 1 || h > 8) return false;                 // BlockSize 2..17 (window 3..17)
-  if (j.maxdisp < 1 || plan_for(j.maxdisp, cols_per_lane(h)).nw == 0) return false;
   if (j.w < 1 || j.h < 1) return false;
-  return true;
+  return plan_for(j.block / 2, j.maxdisp).nw != 0;  // BlockSize 2..17, candidates fit the wave budget
 }
 
 hipError_t launch_fast(const Job& j, hipStream_t s)
 {
   if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
   const int h = j.block / 2;
-  const int p = cols_per_lane(h);
-  const Plan pl = plan_for(j.maxdisp, p);
-#define SADHIP_CASE(PP, NDD, HH) if (p == PP && pl.nd == NDD && h == HH) return launch_t<PP, NDD, HH>(j, pl, s)
-  SADHIP_CASE(4, 12, 1); SADHIP_CASE(4, 12, 2); SADHIP_CASE(4, 12, 3); SADHIP_CASE(4, 12, 4);
-  SADHIP_CASE(4, 8, 1);  SADHIP_CASE(4, 8, 2);  SADHIP_CASE(4, 8, 3);  SADHIP_CASE(4, 8, 4);
-  SADHIP_CASE(8, 12, 4); SADHIP_CASE(8, 12, 5); SADHIP_CASE(8, 12, 6); SADHIP_CASE(8, 12, 7); SADHIP_CASE(8, 12, 8);
+  const Plan pl = plan_for(h, j.maxdisp);
+#define SADHIP_CASE(PP, NDD, HH, PKK) \
+  if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, s)
+  // packed
+  SADHIP_CASE(4, 24, 1, true); SADHIP_CASE(4, 24, 2, true); SADHIP_CASE(4, 24, 3, true); SADHIP_CASE(4, 24, 4, true);
+  SADHIP_CASE(4, 12, 1, true); SADHIP_CASE(4, 12, 2, true); SADHIP_CASE(4, 12, 3, true); SADHIP_CASE(4, 12, 4, true);
+  SADHIP_CASE(4, 8, 1, true);  SADHIP_CASE(4, 8, 2, true);  SADHIP_CASE(4, 8, 3, true);  SADHIP_CASE(4, 8, 4, true);
+  SADHIP_CASE(8, 12, 4, true); SADHIP_CASE(8, 12, 5, true); SADHIP_CASE(8, 12, 6, true); SADHIP_CASE(8, 12, 7, true);
+  // unpacked (window SAD does not fit 16 bits, or forced for comparison)
+  SADHIP_CASE(8, 12, 8, false);
+  SADHIP_CASE(4, 12, 3, false); SADHIP_CASE(4, 12, 4, false);
 #undef SADHIP_CASE
-  return hipErrorInvalidValue;
+  return launch_generic(j, s);
 }
 
 }  // namespace sadhip
