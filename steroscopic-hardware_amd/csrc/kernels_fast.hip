@@ -99,7 +99,7 @@ __device__ __forceinline__ void pk_sad_out2(unsigned& c0, unsigned& c1, unsigned
 }
 __device__ __forceinline__ unsigned from_left(unsigned v)     // lane l <- lane l-1 (lane 0: 0)
 {
-#if defined(SADHIP_EXP) && SADHIP_EXP == 1
+#if defined(SADHIP_EXP) && (SADHIP_EXP == 1 || SADHIP_EXP == 5)
   return v;                                                    // experiment: no cross-lane move
 #elif defined(SADHIP_EXP) && SADHIP_EXP == 2
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // experiment: row_shr:1
@@ -108,7 +108,7 @@ __device__ __forceinline__ unsigned from_left(unsigned v)     // lane l <- lane 
 }
 __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane l+1 (lane 63: 0)
 {
-#if defined(SADHIP_EXP) && SADHIP_EXP == 1
+#if defined(SADHIP_EXP) && (SADHIP_EXP == 1 || SADHIP_EXP == 5)
   return v;
 #elif defined(SADHIP_EXP) && SADHIP_EXP == 2
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);   // experiment: row_shl:1
@@ -217,26 +217,41 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static __device__ __forceinline__ void stage_b(const Pre& r, int q, const int (&jlim)[P], unsigned (&best)[P],
                                                  unsigned dbase)
   {
+    // window sum of column p = own columns + last (h-p) columns of the left lane + first (p+h-P+1)
+    // columns of the right lane.  The DPP adds are issued as two sweeps over p (all "left" pulls,
+    // then all "right" pulls): a DPP instruction that reads a VGPR written by the instruction just
+    // before it costs wait states, so the two adds of one column are kept P instructions apart.
+    unsigned s[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int a = p - H, b = p + H;
       const int lo = a > 0 ? a : 0, hi = b < P - 1 ? b : P - 1;
-      unsigned s = lo == 0 ? r.ps[hi + 1] : r.ps[hi + 1] - r.ps[lo];
-      if (a < 0) s += from_left(r.suf[-a]);                // last (-a) columns of the left lane
-      if (a < 0 && b > P - 1) asm("" : "+v"(s));           // two v_add_u32_dpp, not v_mov_dpp x2 + v_add3
-      if (b > P - 1) s += from_right(r.ps[b - P + 1]);     // first (b-P+1) columns of the right lane
+      s[p] = lo == 0 ? r.ps[hi + 1] : r.ps[hi + 1] - r.ps[lo];
+      if (a < 0) s[p] += from_left(r.suf[-a]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));        // v_add_u32_dpp twice, not v_mov_dpp x2 + v_add3
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (p + H > P - 1) s[p] += from_right(r.ps[p + H - P + 1]);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#if defined(SADHIP_EXP) && (SADHIP_EXP == 3 || SADHIP_EXP == 5)
+      best[p] += s[p]; continue;                                  // experiment: no key build / min
+#endif
       if constexpr (PK) {
-        unsigned ke = (s << 16) | (dbase + 2 * q);           // v_lshl_or_b32
-        unsigned ko = (s & 0xffff0000u) | (dbase + 2 * q + 1); // v_and_or_b32
+        unsigned ke = (s[p] << 16) | (dbase + 2 * q);             // v_lshl_or_b32
+        unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
         if (MASK) {
           ke = (2 * q > jlim[p]) ? KEY_INVALID : ke;
           ko = (2 * q + 1 > jlim[p]) ? KEY_INVALID : ko;
         }
         const unsigned m = ke < ko ? ke : ko;
-        best[p] = m < best[p] ? m : best[p];                 // v_min3_u32
+        best[p] = m < best[p] ? m : best[p];                      // v_min3_u32
       } else {
-        if (MASK) s = (q > jlim[p]) ? KEY_INVALID : s;       // d > min(D, x-h): not a candidate
-        best[p] = s < best[p] ? s : best[p];
+        unsigned k = s[p];
+        if (MASK) k = (q > jlim[p]) ? KEY_INVALID : k;            // d > min(D, x-h): not a candidate
+        best[p] = k < best[p] ? k : best[p];
       }
     }
   }
@@ -472,7 +487,7 @@ Plan plan_for(int h, int maxdisp)
   const int cands = maxdisp + 1;
   const int max_waves = (pk || p == 4) ? 15 : 11;               // + 1 helper wave per workgroup
   int best_waste = 1 << 30;
-  for (int nd : {24, 12, 8}) {
+  for (int nd : {12, 24, 8}) {                               // ties: 12 (measured fastest)
     if (force_nd && force_nd != nd) continue;
     if (nd == 24 && !(pk && p == 4)) continue;
     if (nd == 8 && p == 8) continue;

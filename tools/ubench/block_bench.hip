@@ -6,54 +6,38 @@
 #include <cstdio>
 using namespace sadhip;
 
-template <int P, int ND, int H, int MODE>
-__global__ void __launch_bounds__(P == 4 ? 1024 : 768) k_block(unsigned* io, int iters)
+template <int P, int ND, int H, int MODE, bool PK>
+__global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
 {
-  using K = Cw<P, ND, H>;
+  using K = Cw<P, ND, H, PK>;
+  constexpr int NC = K::NC;
   extern __shared__ __attribute__((aligned(16))) unsigned smem[];
-  unsigned C[P][ND]; int jlim[P]; unsigned best[P];
-  for (int p = 0; p < P; ++p) { jlim[p] = 100; best[p] = 0xffffffffu; for (int q = 0; q < ND; ++q) C[p][q] = io[(threadIdx.x * P + p) * ND + q]; }
+  unsigned C[P][NC]; int jlim[P]; unsigned best[P];
+  for (int p = 0; p < P; ++p) { jlim[p] = 100; best[p] = 0xffffffffu; for (int q = 0; q < NC; ++q) C[p][q] = io[(threadIdx.x * P + p) * NC + q] & 0xff00ff; }
   for (int i = threadIdx.x; i < 4096; i += blockDim.x) smem[i] = io[i] & 0xffff;
   __syncthreads();
   const uint4* l = reinterpret_cast<const uint4*>(smem + 4 * (threadIdx.x & 63));
   const uint4* r = reinterpret_cast<const uint4*>(smem + 1024 + 4 * (threadIdx.x & 63));
   for (int it = 0; it < iters; ++it) {
     if (MODE & 1) K::update_columns(C, l, r, l + 64, r + 64);
-    if (MODE & 8) {                                   // update arithmetic only: operands already in registers
-      unsigned li[P], ri[P + ND];
-      for (int p = 0; p < P; ++p) li[p] = best[p & 3] + p;
-      for (int m = 0; m < P + ND; ++m) ri[m] = jlim[m & 3] + m;
-      for (int p = 0; p < P; ++p) for (int q = 0; q < ND; ++q) sad_acc(C[p][q], li[p], ri[p + ND - 1 - q]);
-      for (int p = 0; p < P; ++p) for (int q = 0; q < ND; q += 4)
-        sad_sub4(C[p][q], C[p][q + 1], C[p][q + 2], C[p][q + 3], li[p], ri[p + ND - 1 - q], ri[p + ND - 2 - q], ri[p + ND - 3 - q], ri[p + ND - 4 - q]);
-    }
-    if (MODE & 16) {                                  // in-row sads only
-      unsigned li[P], ri[P + ND];
-      for (int p = 0; p < P; ++p) li[p] = best[p & 3] + p;
-      for (int m = 0; m < P + ND; ++m) ri[m] = jlim[m & 3] + m;
-      for (int p = 0; p < P; ++p) for (int q = 0; q < ND; ++q) sad_acc(C[p][q], li[p], ri[p + ND - 1 - q]);
-      for (int p = 0; p < P; ++p) for (int q = 0; q < ND; ++q) sad_acc(C[p][q], li[p], ri[p + ND - 1 - q]);
-    }
-    if (MODE & 2) K::template reduce_row<false>(C, jlim, best);
-    if (MODE & 4) K::template reduce_row<true>(C, jlim, best);
     C[0][0] += best[0] & 1;      // keep a dependency so nothing is hoisted
   }
   unsigned acc = 0;
-  for (int p = 0; p < P; ++p) { acc ^= best[p]; for (int q = 0; q < ND; ++q) acc ^= C[p][q]; }
+  for (int p = 0; p < P; ++p) { acc ^= best[p]; for (int q = 0; q < NC; ++q) acc ^= C[p][q]; }
   io[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-template <int P, int ND, int H, int MODE>
+template <int P, int ND, int H, int MODE, bool PK>
 void run(const char* name, int nw, int wgs_per_cu)
 {
   hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
   const int blocks = pr.multiProcessorCount * wgs_per_cu, iters = 2000;
   unsigned* d; hipMalloc(&d, (size_t)blocks * 1024 * 64 * 4); hipMemset(d, 1, (size_t)blocks * 1024 * 64 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k_block<P, ND, H, MODE><<<blocks, 64 * nw, 32768>>>(d, 10);
+  k_block<P, ND, H, MODE, PK><<<blocks, 64 * nw, 32768>>>(d, 10);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k_block<P, ND, H, MODE><<<blocks, 64 * nw, 32768>>>(d, iters);
+  k_block<P, ND, H, MODE, PK><<<blocks, 64 * nw, 32768>>>(d, iters);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double waves_per_simd = (double)nw * wgs_per_cu / 4.0;
@@ -65,20 +49,13 @@ void run(const char* name, int nw, int wgs_per_cu)
 
 int main()
 {
-  run<4, 12, 4, 1>("P4 ND12 H4 update", 6, 2);
-  run<4, 12, 4, 8>("P4 ND12 H4 update (no LDS)", 6, 2);
-  run<4, 12, 4, 16>("P4 ND12 H4 96 sads (no LDS)", 6, 2);
-  run<4, 12, 4, 16>("P4 ND12 H4 96 sads (no LDS)", 4, 4);
-  run<4, 12, 4, 16>("P4 ND12 H4 96 sads (no LDS)", 4, 1);
-  run<4, 12, 4, 1>("P4 ND12 H4 update", 4, 4);
-  run<4, 12, 4, 1>("P4 ND12 H4 update", 4, 1);
-  run<4, 12, 4, 2>("P4 ND12 H4 reduce", 6, 2);
-  run<4, 12, 4, 4>("P4 ND12 H4 reduce(mask)", 6, 2);
-  run<4, 12, 4, 3>("P4 ND12 H4 update+reduce", 6, 2);
-  run<4, 12, 4, 3>("P4 ND12 H4 update+reduce", 4, 4);
-  run<4, 12, 4, 3>("P4 ND12 H4 update+reduce", 4, 1);
-  run<4, 8, 4, 3>("P4 ND8 H4 update+reduce", 9, 2);
-  run<8, 12, 4, 3>("P8 ND12 H4 update+reduce", 6, 2);
-  run<8, 12, 8, 3>("P8 ND12 H8 update+reduce", 6, 2);
+  run<4, 24, 4, 32, true>("packed P4 ND24 perturb only", 3, 4);
+  run<4, 24, 4, 34, true>("packed P4 ND24 perturb+reduce", 3, 4);
+  run<4, 24, 4, 36, true>("packed P4 ND24 perturb+reduce(mask)", 3, 4);
+  run<4, 24, 4, 35, true>("packed P4 ND24 perturb+update+reduce", 3, 4);
+  run<4, 12, 4, 32, true>("packed P4 ND12 perturb only", 6, 4);
+  run<4, 12, 4, 34, true>("packed P4 ND12 perturb+reduce", 6, 4);
+  run<4, 12, 4, 32, false>("unpacked P4 ND12 perturb only", 6, 2);
+  run<4, 12, 4, 34, false>("unpacked P4 ND12 perturb+reduce", 6, 2);
   return 0;
 }
