@@ -4,28 +4,31 @@
 // SURVEY.md section 8 a-1):   out(x,y) = scale(argmin_{d in [0,min(D,max(0,x-h))]} SAD(x,y,d)),
 // first minimum wins, windows clipped to the image.
 //
-// Mapping (why it looks like this -- measured on MI355X, tools/ubench/valu_rates.hip):
-//   * the path is integer-VALU bound: v_sad_*/min3/DPP ops cost ~4.2 SIMD-cycles per
-//     wave-instruction, plain v_add/v_sub ~2.3, v_qsad_pk_u16_u8 is quarter rate; one LDS dword
-//     per lane costs as much as two such VALU ops.  So: every |L-R| is one v_sad_u32 with the
-//     accumulate folded in, everything else is adds/subs, and operands stay in registers.
-//   * lane l of a wave owns P=4 adjacent columns; a wave owns ND consecutive disparities for its
-//     256 columns; the NW waves of a workgroup split the disparity range of one tile.
-//   * vertical: each lane keeps the column sums C[p][q] of its (column, disparity) pairs in
-//     registers and slides them down the strip: + |L-R| of the row entering the window (v_sad_u32
-//     with accumulator), - |L-R| of the row leaving it (v_sad_u32 + v_sub).
-//   * horizontal: the (2h+1)-wide window sum of C is formed from in-lane prefix sums plus 2h
-//     values fetched from the two neighbour lanes with DPP wave_shr:1 / wave_shl:1 (no LDS).
-//   * argmin: all values are pre-scaled by 2^KSH and every window is made to contain exactly one
-//     column whose C carries the bias d, so the window sum IS the key (SAD << KSH) | d; the
-//     first-minimum rule (strict '<', sad.go:79) is then a plain unsigned min (v_min3_u32).
-//   * waves merge their per-pixel minima with ds_min_u32 into a row buffer in LDS; after the
-//     one barrier per row the workgroup converts key -> d -> best*255/D (LUT) and stores u8.
-//   * image rows stream through an LDS ring (2h+3 rows of u32 pre-shifted pixels), prefetched
-//     one row ahead through registers.  ND is a multiple of 4 and the R part of a ring row is
-//     offset so that every lane's operands are 16-byte aligned: all operand reads are
-//     ds_read_b128, which is bank-conflict free at a lane stride of 16 bytes (a ds_read_b32 at
-//     that stride is a 4-way conflict: measured 72 % of LDS cycles).
+// Mapping (why it looks like this -- measured on MI355X, tools/ubench/*.hip):
+//   * the path is integer-VALU bound: v_sad_*/min3/DPP/perm ops cost ~4.3 SIMD-cycles per
+//     wave-instruction, plain v_add/v_sub ~2.5, v_qsad_pk_u16_u8 is quarter rate; one LDS dword per
+//     lane costs as much as two such VALU ops.  So: every |L-R| is one SAD instruction with the
+//     accumulate folded in, everything else is adds/subs, operands stay in registers.
+//   * lane l of a wave owns P (4 or 8) adjacent columns; a compute wave owns ND consecutive
+//     disparities for its 64*P columns; the NW compute waves of a workgroup split the disparity
+//     range of one tile; one more wave (the helper) streams rows and writes output.
+//   * vertical: each lane keeps the column sums of its (column, disparity) pairs in registers and
+//     slides them down the strip: + |L-R| of the row entering the window, - |L-R| of the row
+//     leaving it.  Packed variant (window SAD < 65536): two adjacent disparities share a register
+//     as u16 halves (v_sad_u8 -> low half, v_sad_hi_u8 -> high half); unpacked: u32 + v_sad_u32.
+//   * horizontal: the (2h+1)-wide window sum = in-lane prefix sums + 2h values fetched from the
+//     two neighbour lanes with v_add_u32_dpp wave_shr:1 / wave_shl:1 (no LDS).
+//   * argmin: strict-'<' first minimum (sad.go:79) = unsigned min of keys (SAD << 16) | d
+//     (v_min3_u32).  Packed: v_lshl_or_b32 / v_perm_b32 build the two keys of a register.
+//     Unpacked: pixels are pre-scaled by 2^KSH and every window contains exactly one column whose
+//     sum starts at d, so the window sum IS the key.
+//   * compute waves merge their per-pixel minima with ds_min_u32 into a row buffer in LDS; after
+//     the one barrier per row the helper wave maps key -> d -> best*255/D (LUT) and stores u8.
+//   * image rows stream through an LDS ring (2h+3 rows, one u32 per pixel), loaded by the helper
+//     two rows ahead.  ND is a multiple of 4 and the R part of a ring row is offset so that every
+//     lane's operands are 16-byte aligned: all operand reads are ds_read_b128, bank-conflict free
+//     at a lane stride of 16 bytes (ds_read_b32 at that stride was a 4-way conflict: 72 % of LDS
+//     cycles in the first version).
 #include "sadhip_kernels.h"
 #include <cstdlib>
 
