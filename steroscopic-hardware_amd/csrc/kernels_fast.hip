@@ -378,7 +378,9 @@ struct Cw {                                         // P columns per lane: 4 (h 
         }
         unsigned* rb = rowbest + (t & 1) * TW + lofs;
 #pragma unroll
-        for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]);          // ds_min_u32
+        for (int p = 0; p < P; ++p)
+          if (!(a.dbg & 32)) atomicMin(rb + p, best[p]);                  // ds_min_u32
+          else asm volatile("" :: "v"(best[p]));
       }
       if (!(a.dbg & 16)) __syncthreads();
       slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
@@ -437,26 +439,31 @@ struct Cw {                                         // P columns per lane: 4 (h 
         if (x + 3 >= ox0 && x + 3 < ox1) orow[x + 3] = v3;
       }
     };
+    // two register sets alternate (loop unrolled by two) so that a row's loads are only waited
+    // for one full step after they were issued
     unsigned pfa[MAXV], pfb[MAXV];
     load_row(ys - H + 1, pfa);                            // row that step 0 lands
     int slot_next = 1 == NR ? 0 : 1;
-    for (int t = 0; t < nsteps; ++t) {
-      const bool have_next = t + 1 < nsteps;
-      if (t + 2 < nsteps) load_row(ys - H + t + 2, pfb);  // two rows ahead
+    auto step = [&](int t, unsigned (&land)[MAXV], unsigned (&fill)[MAXV]) {
+      if (t + 2 < nsteps) load_row(ys - H + t + 2, fill); // two rows ahead
       if (t > 2 * H && !(a.dbg & 4)) finalize(t - 1);
-      if (have_next) {
+      if (t + 1 < nsteps) {
         unsigned* dst = ring + slot_next * ROWW;
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
           const int i = lane + 64 * v;
-          if (i < nvals) dst[i] = pfa[v] << a.pixshift;
+          if (i < nvals) dst[i] = land[v] << a.pixshift;
         }
       }
       if (!(a.dbg & 16)) __syncthreads();
-#pragma unroll
-      for (int v = 0; v < MAXV; ++v) pfa[v] = pfb[v];
       slot_next = slot_next + 1 == NR ? 0 : slot_next + 1;
+    };
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {
+      step(t, pfa, pfb);
+      step(t + 1, pfb, pfa);
     }
+    if (t < nsteps) step(t, pfa, pfb);
     if (!(a.dbg & 4)) finalize(nsteps - 1);
     __syncthreads();
   }
