@@ -40,16 +40,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0, help="sadhip flags (2 = force generic kernel)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single GPU: every rank uses cuda:0 and the collectives run "
+                         "over gloo on CPU tensors (the real N-GPU run uses nccl = RCCL, one GPU per rank)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import steroscopic_hardware_amd as sha
 
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.rehearse_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist, rank, world, local = sha.shard.init("nccl", dev)
+    cdev = torch.device("cpu") if args.rehearse_one_gpu else dev          # where collectives run
+    dist, rank, world, _ = sha.shard.init("gloo" if args.rehearse_one_gpu else "nccl", dev)
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -57,7 +61,7 @@ def main():
             sys.exit(2)
 
     # parameters: rank 0 decides, everyone else receives them (2 x int32 over RCCL/xGMI)
-    block, maxdisp = sha.shard.broadcast_params(dist, rank, BLOCK, MAXDISP, dev)
+    block, maxdisp = sha.shard.broadcast_params(dist, rank, BLOCK, MAXDISP, cdev)
 
     F = args.frames_per_gpu
     seeds = sha.shard.frame_seeds(rank, world, F)                 # frame i -> GPU i mod G
@@ -87,7 +91,7 @@ def main():
     torch.cuda.synchronize(dev)
     sha.shard.barrier(dist)
     torch.cuda.synchronize(dev)
-    elapsed = sha.shard.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    elapsed = sha.shard.max_over_ranks(dist, time.perf_counter() - t0, cdev)
     launch_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     avg_launch_ms = sum(launch_ms) / len(launch_ms)
 
