@@ -62,6 +62,11 @@ extern "C" {
 /* sadhip_disparity_* "flags" argument */
 #define SADHIP_FLAG_RAW        1u   /* store best d itself (clamped to 255) instead of best*255/maxdisp */
 #define SADHIP_FLAG_FORCE_GENERIC 2u /* diagnostics: use the generic kernel even where the fast one applies */
+/* Hardware-mirror modes: compute with the semantics of the reference's OTHER golden models instead
+ * of pkg/despair's, raw d output, so the FPGA testbench fixtures can be regenerated at any size
+ * (SURVEY.md section 8 f-4).  Mutually exclusive; block = the models' WIN, maxdisp = MAX_DISP. */
+#define SADHIP_FLAG_MIRROR_SADC   4u /* hardware/sad.c:66-106 (interior only, xr<0 terms skipped) */
+#define SADHIP_FLAG_MIRROR_TESTPY 8u /* hardware/test.py:262-294 compute_disparity_patch (zero padding) */
 
 typedef struct sadhip_ctx sadhip_ctx;   /* opaque per-device context */
 

@@ -21,6 +21,8 @@ OK = 0
 ERR_NULL, ERR_DIMS, ERR_STRIDE, ERR_BLOCK, ERR_MAXDISP, ERR_REGION, ERR_BATCH, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = range(1, 12)
 FLAG_RAW = 1
 FLAG_FORCE_GENERIC = 2
+FLAG_MIRROR_SADC = 4
+FLAG_MIRROR_TESTPY = 8
 MAX_BLOCK = 255
 MAX_MAXDISP = 4096
 

@@ -46,6 +46,63 @@ k_disparity_generic(Job j)
   j.out[(size_t)f * j.out_frame_stride + (size_t)(y - j.oy) * j.ostride + (x - j.ox)] = (uint8_t)v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hardware-mirror modes: the two other golden models in the reference,
+// so the GPU can regenerate hardware/exp_disp.mem and hardware/mems/exp_disp_p.mem at any size.
+// Raw best d (u8), no scaling.
+//   mode 1  hardware/sad.c:66-106   interior pixels only (border output 0, calloc :45); every
+//           d in [0,D] is a candidate; window terms with xr < 0 are skipped (:83-85); strict '<'.
+//   mode 2  hardware/test.py:262-294  both images zero-padded by win/2, the padded right image
+//           shifted by d with zero fill, box sum of |L-R|, strict '<'; output for every pixel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_disparity_mirror(Job j, int mode)
+{
+  const int x = j.x0 + blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = j.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int f = blockIdx.z;
+  if (x >= j.x1 || y >= j.y1) return;
+  const uint8_t* __restrict__ L = j.left + (size_t)f * j.left_frame_stride;
+  const uint8_t* __restrict__ R = j.right + (size_t)f * j.right_frame_stride;
+  const int m = j.block / 2;
+  int best = 0;
+  if (mode == 1 && (x < m || x >= j.w - m || y < m || y >= j.h - m)) {
+    best = 0;                                                   // sad.c:68-69: border stays 0
+  } else {
+    unsigned best_sad = 0xffffffffu;
+    for (int d = 0; d <= j.maxdisp; ++d) {
+      unsigned sad = 0;
+      for (int dy = -m; dy <= m; ++dy) {
+        const int yy = y + dy;
+        const bool row_in = yy >= 0 && yy < j.h;
+        for (int dx = -m; dx <= m; ++dx) {
+          const int xl = x + dx, xr = xl - d;
+          if (mode == 1) {
+            if (xr < 0) continue;                               // sad.c:83-85
+            const int a = L[(size_t)(yy - j.row0) * j.lstride + xl], b = R[(size_t)(yy - j.row0) * j.rstride + xr];
+            sad += (unsigned)(a >= b ? a - b : b - a);
+          } else {
+            const int a = (row_in && xl >= 0 && xl < j.w) ? L[(size_t)(yy - j.row0) * j.lstride + xl] : 0;
+            const int b = (row_in && xr >= 0 && xr < j.w) ? R[(size_t)(yy - j.row0) * j.rstride + xr] : 0;
+            sad += (unsigned)(a >= b ? a - b : b - a);
+          }
+        }
+      }
+      if (sad < best_sad) { best_sad = sad; best = d; }
+    }
+  }
+  j.out[(size_t)f * j.out_frame_stride + (size_t)(y - j.oy) * j.ostride + (x - j.ox)] = (uint8_t)min(best, 255);
+}
+
+hipError_t launch_mirror(const Job& j, int mode, hipStream_t s)
+{
+  const int rw = j.x1 - j.x0, rh = j.y1 - j.y0;
+  if (rw <= 0 || rh <= 0 || j.n <= 0) return hipSuccess;
+  dim3 grid((rw + 63) / 64, (rh + 3) / 4, j.n);
+  hipLaunchKernelGGL(k_disparity_mirror, grid, dim3(256), 0, s, j, mode);
+  return hipGetLastError();
+}
+
 hipError_t launch_generic(const Job& j, hipStream_t s)
 {
   const int rw = j.x1 - j.x0, rh = j.y1 - j.y0;

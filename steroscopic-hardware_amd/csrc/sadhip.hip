@@ -199,6 +199,8 @@ static int check_params(int w, int h, int lstride, int rstride, int block, int m
 
 static hipError_t dispatch(const Job& j, unsigned flags, hipStream_t s)
 {
+  if (flags & SADHIP_FLAG_MIRROR_SADC) return launch_mirror(j, 1, s);
+  if (flags & SADHIP_FLAG_MIRROR_TESTPY) return launch_mirror(j, 2, s);
   if (!(flags & SADHIP_FLAG_FORCE_GENERIC) && fast_supported(j)) return launch_fast(j, s);
   return launch_generic(j, s);
 }

@@ -31,6 +31,9 @@ struct Job {
 // restatement of sad.go:55-94 with u32 accumulators.  Always available.
 hipError_t launch_generic(const Job& j, hipStream_t s);
 
+// Hardware-mirror golden models (mode 1: hardware/sad.c, mode 2: hardware/test.py); raw d output.
+hipError_t launch_mirror(const Job& j, int mode, hipStream_t s);
+
 // Fast kernel (kernels_fast.hip): returns true if it supports the job's parameters.
 bool fast_supported(const Job& j);
 hipError_t launch_fast(const Job& j, hipStream_t s);

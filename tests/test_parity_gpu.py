@@ -68,6 +68,23 @@ def test_hardware_fixture_regions(ctx, hwfx, flags):
     assert np.array_equal(got[hs:128 - hs, D + hs:128 - hs], hwfx["exp_disp_sadc"][hs:128 - hs, D + hs:128 - hs])
 
 
+def test_hardware_mirror_modes_regenerate_the_reference_fixtures(ctx, hwfx, refout):
+    """f-4: with the semantics of hardware/sad.c and hardware/test.py the GPU reproduces the
+    reference's committed golden files in full (every pixel, not only the region shared with Go)."""
+    for k in range(4):
+        got = ctx.disparity(hwfx["patch_L"][k], hwfx["patch_R"][k], 15, 64, capi.FLAG_MIRROR_TESTPY)
+        assert np.array_equal(got, hwfx["exp_disp_p"][k])                    # hardware/mems/exp_disp_p.mem
+    got = ctx.disparity(hwfx["patch_L"][1], hwfx["patch_R"][1], 15, 64, capi.FLAG_MIRROR_SADC)
+    assert np.array_equal(got, hwfx["exp_disp_sadc"])                        # hardware/exp_disp.mem
+    for i in range(int(refout["testpy_ncases"][0])):                         # test.py run on seeded inputs
+        win, maxd = (int(v) for v in refout[f"testpy_case{i}_params"])
+        got = ctx.disparity(refout[f"testpy_case{i}_L"], refout[f"testpy_case{i}_R"], win, maxd, capi.FLAG_MIRROR_TESTPY)
+        assert np.array_equal(got, refout[f"testpy_case{i}_out"])
+    L, R = sha.synth.synth_pair(31, 200, 90)                                 # and at another size vs the CPU mirrors
+    assert np.array_equal(ctx.disparity(L, R, 9, 48, capi.FLAG_MIRROR_SADC), oracle.mirror_sadc(L, R, 9, 48))
+    assert np.array_equal(ctx.disparity(L, R, 9, 48, capi.FLAG_MIRROR_TESTPY), oracle.mirror_testpy(L, R, 9, 48))
+
+
 # ---- adversarial / edge shapes (SURVEY.md section 7 step 3, section 8d) ------------------------
 EDGE = [  # (w, h, block, maxdisp)
     (1, 1, 7, 32), (5, 4, 15, 16), (40, 33, 9, 64), (33, 20, 16, 64), (50, 40, 31, 256),
