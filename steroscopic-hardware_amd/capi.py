@@ -191,7 +191,7 @@ class Context:
                                                 x0, y0, x1, y1, out.ctypes.data if out.size else np.empty(1, np.uint8).ctypes.data))
         return out
 
-    def disparity_batch(self, lefts, rights, block, maxdisp, flags=0):
+    def disparity_batch(self, lefts, rights, block, maxdisp, flags=0, outs=None):
         n = len(lefts)
         assert len(rights) == n
         if n == 0:
@@ -203,7 +203,9 @@ class Context:
             _img(a, "frame")
             assert a.shape == (h, w)
         assert all(a.strides[0] == ls for a in lefts) and all(a.strides[0] == rs for a in rights)
-        outs = [np.empty((h, w), np.uint8) for _ in range(n)]
+        if outs is None:
+            outs = [np.empty((h, w), np.uint8) for _ in range(n)]
+        assert len(outs) == n and all(o.shape == (h, w) and o.strides == (w, 1) for o in outs)
         pa = (C.c_void_p * n)(*[a.ctypes.data for a in lefts])
         pb = (C.c_void_p * n)(*[a.ctypes.data for a in rights])
         po = (C.c_void_p * n)(*[a.ctypes.data for a in outs])

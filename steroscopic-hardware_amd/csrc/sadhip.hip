@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 
@@ -91,6 +92,12 @@ struct sadhip_ctx {
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* h_scratch = nullptr; size_t h_scratch_bytes = 0;
   float last_kernel_ms = 0.f, last_total_ms = 0.f;
+  // Host copies.  Default: hipMemcpy2DAsync straight from / to the caller's (pageable) buffers --
+  // the runtime's own staging measured 2.2x faster than memcpy into pinned planes + linear copies
+  // (0.27 vs 0.58 ms per 1080p pair; 6 700 vs 2 900 pairs/s pipelined).  Every host entry point
+  // synchronises its stream before returning, so no caller pointer outlives the call either way.
+  // SADHIP_PINNED_STAGING=1 selects the pinned-plane path (kept for comparison).
+  bool pinned_staging = false;
   std::mutex mu;
 };
 
@@ -148,14 +155,17 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
   c->device = device; c->max_w = max_w; c->max_h = max_h; c->max_batch = max_batch;
   c->pitch = align_up((size_t)max_w, 256);
   c->plane = c->pitch * (size_t)max_h;
+  c->pinned_staging = getenv("SADHIP_PINNED_STAGING") != nullptr;
   for (auto& s : c->slot) {
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&s.k0);
     if (e == hipSuccess) e = hipEventCreate(&s.k1);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hL, c->plane, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hR, c->plane, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hO, c->plane, hipHostMallocDefault);
+    if (c->pinned_staging) {
+      if (e == hipSuccess) e = hipHostMalloc((void**)&s.hL, c->plane, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipHostMalloc((void**)&s.hR, c->plane, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipHostMalloc((void**)&s.hO, c->plane, hipHostMallocDefault);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&s.dL, c->plane);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dR, c->plane);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dO, c->plane);
@@ -229,16 +239,25 @@ using clk = std::chrono::steady_clock;
 
 // One frame (or band of a frame) through slot s: stage -> H2D -> kernel -> D2H, all async on
 // the slot's stream.  rows [band0,band1) of the inputs are uploaded.
+// row pitch of the staging planes for a w-wide frame (<= the context's allocation pitch)
+static inline size_t pitch_for(int w) { return align_up((size_t)w, 256); }
+
 static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint8_t* right,
                          int w, int h, int lstride, int rstride, int block, int maxdisp, unsigned flags,
                          int x0, int y0, int x1, int y1, int band0, int band1)
 {
-  const size_t pitch = c->pitch;
+  const size_t pitch = pitch_for(w);
+  const bool direct = !c->pinned_staging;   // default: 2-D copies straight from / to the caller's memory
+  if (direct) {
+    HIPTRY(hipMemcpy2DAsync(s.dL, pitch, left + (size_t)band0 * lstride, lstride, w, band1 - band0, hipMemcpyHostToDevice, s.stream));
+    HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, w, band1 - band0, hipMemcpyHostToDevice, s.stream));
+  } else {
   stage_rows(s.hL, pitch, left, lstride, w, band0, band1);
   stage_rows(s.hR, pitch, right, rstride, w, band0, band1);
   const size_t bytes = (size_t)(band1 - band0) * pitch;
   HIPTRY(hipMemcpyAsync(s.dL, s.hL, bytes, hipMemcpyHostToDevice, s.stream));
   HIPTRY(hipMemcpyAsync(s.dR, s.hR, bytes, hipMemcpyHostToDevice, s.stream));
+  }
   Job j{};
   j.left = s.dL; j.right = s.dR; j.out = s.dO;
   j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = c->plane;
@@ -251,20 +270,25 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
   HIPTRY(hipEventRecord(s.k0, s.stream));
   HIPTRY(dispatch(j, flags, s.stream));
   HIPTRY(hipEventRecord(s.k1, s.stream));
-  HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)(y1 - y0) * pitch, hipMemcpyDeviceToHost, s.stream));
+  if (!direct) HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)(y1 - y0) * pitch, hipMemcpyDeviceToHost, s.stream));
   return SADHIP_OK;
 }
 
-static int finish_frame(sadhip_ctx* c, Slot& s, int x0, int y0, int x1, int y1, uint8_t* out, int ostride,
+static int finish_frame(sadhip_ctx* c, Slot& s, int w, int x0, int y0, int x1, int y1, uint8_t* out, int ostride,
                         float* kernel_ms)
 {
+  const size_t pitch = pitch_for(w);
+  const bool direct = !c->pinned_staging;
+  if (direct)
+    HIPTRY(hipMemcpy2DAsync(out, ostride, s.dO + x0, pitch, x1 - x0, y1 - y0, hipMemcpyDeviceToHost, s.stream));
   HIPTRY(hipStreamSynchronize(s.stream));
   float ms = 0.f;
   HIPTRY(hipEventElapsedTime(&ms, s.k0, s.k1));
   if (kernel_ms) *kernel_ms += ms;
   const int rw = x1 - x0;
-  for (int r = 0; r < y1 - y0; ++r)
-    memcpy(out + (size_t)r * ostride, s.hO + (size_t)r * c->pitch + x0, (size_t)rw);
+  if (!direct)
+    for (int r = 0; r < y1 - y0; ++r)
+      memcpy(out + (size_t)r * ostride, s.hO + (size_t)r * pitch + x0, (size_t)rw);
   return SADHIP_OK;
 }
 
@@ -288,7 +312,7 @@ extern "C" int sadhip_disparity_region_u8(sadhip_ctx* ctx, const uint8_t* left, 
   if (int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags,
                              x0, y0, x1, y1, band0, band1)) return st;
   float kms = 0.f;
-  if (int st = finish_frame(ctx, s, x0, y0, x1, y1, out_region, x1 - x0, &kms)) return st;
+  if (int st = finish_frame(ctx, s, w, x0, y0, x1, y1, out_region, x1 - x0, &kms)) return st;
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
   return SADHIP_OK;
@@ -309,7 +333,7 @@ extern "C" int sadhip_disparity_u8(sadhip_ctx* ctx, const uint8_t* left, const u
   if (int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags,
                              0, 0, w, h, 0, h)) return st;
   float kms = 0.f;
-  if (int st = finish_frame(ctx, s, 0, 0, w, h, out, ostride, &kms)) return st;
+  if (int st = finish_frame(ctx, s, w, 0, 0, w, h, out, ostride, &kms)) return st;
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
   return SADHIP_OK;
@@ -336,6 +360,16 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
   float kms = 0.f;
   // two-slot software pipeline: while slot A's frame is on the GPU, the host stages and
   // enqueues the next frame on slot B, then drains A.
+  static const bool seq = getenv("SADHIP_BATCH_SEQ") != nullptr;      // tuning aid: no cross-frame overlap
+  if (seq) {
+    for (int i = 0; i < n; ++i) {
+      if (int st = enqueue_frame(ctx, ctx->slot[0], lefts[i], rights[i], w, h, lstride, rstride, block, maxdisp, flags, 0, 0, w, h, 0, h)) return st;
+      if (int st = finish_frame(ctx, ctx->slot[0], w, 0, 0, w, h, outs[i], ostride, &kms)) return st;
+    }
+    ctx->last_kernel_ms = kms;
+    ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+    return SADHIP_OK;
+  }
   constexpr int S = sadhip_ctx::kSlots;
   for (int i = 0; i < n + S - 1; ++i) {
     if (i < n) {
@@ -347,7 +381,7 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
     }
     const int d = i - (S - 1);
     if (d >= 0) {
-      if (int st = finish_frame(ctx, ctx->slot[d % S], 0, 0, w, h, outs[d], ostride, &kms)) {
+      if (int st = finish_frame(ctx, ctx->slot[d % S], w, 0, 0, w, h, outs[d], ostride, &kms)) {
         for (auto& s : ctx->slot) (void)hipStreamSynchronize(s.stream);
         return st;
       }
@@ -497,20 +531,21 @@ extern "C" int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
   Slot& s = ctx->slot[0];
   HIPTRY(hipMemcpyAsync(ds, hs, 2 * pbytes, hipMemcpyHostToDevice, s.stream));
   HIPTRY(hipEventRecord(s.k0, s.stream));
-  HIPTRY(launch_gray(ds, channels, w, h, (int)prow, s.dL, (int)ctx->pitch, s.stream));
-  HIPTRY(launch_gray(ds + pbytes, channels, w, h, (int)prow, s.dR, (int)ctx->pitch, s.stream));
+  const size_t gpitch = pitch_for(w);
+  HIPTRY(launch_gray(ds, channels, w, h, (int)prow, s.dL, (int)gpitch, s.stream));
+  HIPTRY(launch_gray(ds + pbytes, channels, w, h, (int)prow, s.dR, (int)gpitch, s.stream));
   Job j{};
   j.left = s.dL; j.right = s.dR; j.out = s.dO;
   j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = ctx->plane;
-  j.lstride = j.rstride = j.ostride = (int)ctx->pitch;
+  j.lstride = j.rstride = j.ostride = (int)gpitch;
   j.n = 1; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
   j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.ox = 0; j.oy = 0;
   j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
   HIPTRY(dispatch(j, flags, s.stream));
   HIPTRY(hipEventRecord(s.k1, s.stream));
-  HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)h * ctx->pitch, hipMemcpyDeviceToHost, s.stream));
+  if (ctx->pinned_staging) HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)h * gpitch, hipMemcpyDeviceToHost, s.stream));
   float kms = 0.f;
-  if (int st = finish_frame(ctx, s, 0, 0, w, h, out, ostride, &kms)) return st;
+  if (int st = finish_frame(ctx, s, w, 0, 0, w, h, out, ostride, &kms)) return st;
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
   return SADHIP_OK;

@@ -11,10 +11,12 @@ Ls = [pairs[i % 4][0] for i in range(N)]; Rs = [pairs[i % 4][1] for i in range(N
 ctx = sha.capi.Context(0, W, H, 1)
 ctx.disparity(Ls[0], Rs[0], B, D)
 t0 = time.perf_counter()
-for i in range(8): ctx.disparity(Ls[i], Rs[i], B, D)
+o1 = np.zeros((H, W), np.uint8)
+for i in range(8): ctx.disparity(Ls[i], Rs[i], B, D, out=o1)
 t1 = time.perf_counter()
 k, t = ctx.last_timing()
 print(f"sadhip_disparity_u8 (one pair, host buffers, synchronous): {(t1-t0)/8*1e3:.3f} ms/pair wall; last call kernel {k:.3f} ms, total {t:.3f} ms")
-ctx.disparity_batch(Ls[:4], Rs[:4], B, D)
-t0 = time.perf_counter(); ctx.disparity_batch(Ls, Rs, B, D); t1 = time.perf_counter()
+outs = [np.zeros((H, W), np.uint8) for _ in range(N)]          # pre-touched output pages
+ctx.disparity_batch(Ls, Rs, B, D, outs=outs)
+t0 = time.perf_counter(); ctx.disparity_batch(Ls, Rs, B, D, outs=outs); t1 = time.perf_counter()
 print(f"sadhip_disparity_batch_u8 ({N} pairs, double-buffered H2D/kernel/D2H): {(t1-t0)/N*1e3:.3f} ms/pair = {N/(t1-t0):.0f} pairs/s (PCIe-inclusive)")
