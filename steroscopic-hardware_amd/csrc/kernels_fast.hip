@@ -102,20 +102,10 @@ __device__ __forceinline__ void pk_sad_out2(unsigned& c0, unsigned& c1, unsigned
 }
 __device__ __forceinline__ unsigned from_left(unsigned v)     // lane l <- lane l-1 (lane 0: 0)
 {
-#if defined(SADHIP_EXP) && (SADHIP_EXP == 1 || SADHIP_EXP == 5)
-  return v;                                                    // experiment: no cross-lane move
-#elif defined(SADHIP_EXP) && SADHIP_EXP == 2
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // experiment: row_shr:1
-#endif
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);    // wave_shr:1 bound_ctrl:0
 }
 __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane l+1 (lane 63: 0)
 {
-#if defined(SADHIP_EXP) && (SADHIP_EXP == 1 || SADHIP_EXP == 5)
-  return v;
-#elif defined(SADHIP_EXP) && SADHIP_EXP == 2
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);   // experiment: row_shl:1
-#endif
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
 }
 
@@ -239,9 +229,6 @@ struct Cw {                                         // P columns per lane: 4 (h 
       if (p + H > P - 1) s[p] += from_right(r.ps[p + H - P + 1]);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-#if defined(SADHIP_EXP) && (SADHIP_EXP == 3 || SADHIP_EXP == 5)
-      best[p] += s[p]; continue;                                  // experiment: no key build / min
-#endif
       if constexpr (PK) {
         unsigned ke = (s[p] << 16) | (dbase + 2 * q);             // v_lshl_or_b32
         unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
@@ -469,9 +456,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
   }
 };
 
-// 1024-thread bound = 128 VGPRs; the unpacked P = 8 kernel keeps 96 column sums: 768 threads (168 VGPRs)
-template <int P, int ND, int H, bool PK>
-__global__ void __launch_bounds__((PK || P == 4) ? 1024 : 768) k_colwave(CwArgs a) { Cw<P, ND, H, PK>::run(a); }
+// WB = workgroup-size bound: 1024 threads -> 128 VGPRs.  The unpacked P = 8 kernel keeps 96 column
+// sums: 512 threads (256 VGPRs, no spills) when the workgroup fits, else 768 (168 VGPRs).
+template <int P, int ND, int H, bool PK, int WB>
+__global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK>::run(a); }
 
 struct Plan { int p, nd, nw; bool pk; };
 
@@ -509,7 +497,7 @@ Plan plan_for(int h, int maxdisp)
   return best;
 }
 
-template <int P, int ND, int H, bool PK>
+template <int P, int ND, int H, bool PK, int WB = 1024>
 hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
 {
   using K = Cw<P, ND, H, PK>;
@@ -547,7 +535,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
     aa.j.left += (size_t)f0 * j.left_frame_stride;
     aa.j.right += (size_t)f0 * j.right_frame_stride;
     aa.j.out += (size_t)f0 * j.out_frame_stride;
-    hipLaunchKernelGGL((k_colwave<P, ND, H, PK>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * (pl.nw + 1)), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * (pl.nw + 1)), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -575,7 +563,8 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
   SADHIP_CASE(4, 8, 1, true);  SADHIP_CASE(4, 8, 2, true);  SADHIP_CASE(4, 8, 3, true);  SADHIP_CASE(4, 8, 4, true);
   SADHIP_CASE(8, 12, 4, true); SADHIP_CASE(8, 12, 5, true); SADHIP_CASE(8, 12, 6, true); SADHIP_CASE(8, 12, 7, true);
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
-  SADHIP_CASE(8, 12, 8, false);
+  if (pl.p == 8 && pl.nd == 12 && h == 8 && !pl.pk)
+    return 64 * (pl.nw + 1) <= 512 ? launch_t<8, 12, 8, false, 512>(j, pl, s) : launch_t<8, 12, 8, false, 768>(j, pl, s);
   SADHIP_CASE(4, 12, 3, false); SADHIP_CASE(4, 12, 4, false);
 #undef SADHIP_CASE
   return launch_generic(j, s);
