@@ -528,7 +528,8 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
   const int ROWW = 2 * K::TW + a.dpad + 1;
-  const size_t lds = (size_t)((K::NR + 1) * ROWW + 2 * K::TW) * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15);
+  const size_t lds = (size_t)((K::NR + 1) * ROWW + 2 * K::TW) * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
+                     + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     CwArgs aa = a;
     aa.j.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
