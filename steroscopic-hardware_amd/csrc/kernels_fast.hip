@@ -109,6 +109,16 @@ __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane 
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
 }
 
+// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also emits
+// s_waitcnt vmcnt(0): the helper wave would then sit at every row barrier until the global loads
+// it has just issued for a LATER row have returned (a full memory latency per row, with every
+// compute wave waiting behind it).  The loads are consumed a step later; hipcc places the
+// vmcnt wait at that use by itself.  "memory" keeps the compiler from moving LDS accesses across.
+__device__ __forceinline__ void wg_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int P, int ND, int H, bool PK>
 struct Cw {                                         // P columns per lane: 4 (h <= 4) or 8 (h <= 8)
   // PK: column sums of disparity pairs packed as u16 halves (window SAD < 65536, i.e. h <= 7)
@@ -369,10 +379,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
           if (!(a.dbg & 32)) atomicMin(rb + p, best[p]);                  // ds_min_u32
           else asm volatile("" :: "v"(best[p]));
       }
-      if (!(a.dbg & 16)) __syncthreads();
+      if (!(a.dbg & 16)) wg_barrier();
       slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
     }
-    __syncthreads();                                      // pairs with the helper's final barrier
+    wg_barrier();                                         // pairs with the helper's final barrier
   }
 
   // ---- helper wave: row streaming + output --------------------------------------------------------
@@ -431,9 +441,11 @@ struct Cw {                                         // P columns per lane: 4 (h 
     unsigned pfa[MAXV], pfb[MAXV];
     load_row(ys - H + 1, pfa);                            // row that step 0 lands
     int slot_next = 1 == NR ? 0 : 1;
+    // Order inside a step matters: hipcc cannot count the conditional loads / stores below, so its
+    // wait before the first use of land[] is vmcnt(0).  Landing first makes that wait cover only
+    // operations issued a whole step earlier (long complete); the loads and stores issued after it
+    // are not waited for until the next step.
     auto step = [&](int t, unsigned (&land)[MAXV], unsigned (&fill)[MAXV]) {
-      if (t + 2 < nsteps) load_row(ys - H + t + 2, fill); // two rows ahead
-      if (t > 2 * H && !(a.dbg & 4)) finalize(t - 1);
       if (t + 1 < nsteps) {
         unsigned* dst = ring + slot_next * ROWW;
 #pragma unroll
@@ -442,7 +454,9 @@ struct Cw {                                         // P columns per lane: 4 (h 
           if (i < nvals) dst[i] = land[v] << a.pixshift;
         }
       }
-      if (!(a.dbg & 16)) __syncthreads();
+      if (t + 2 < nsteps) load_row(ys - H + t + 2, fill); // two rows ahead
+      if (t > 2 * H && !(a.dbg & 4)) finalize(t - 1);
+      if (!(a.dbg & 16)) wg_barrier();
       slot_next = slot_next + 1 == NR ? 0 : slot_next + 1;
     };
     int t = 0;
@@ -452,7 +466,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
     }
     if (t < nsteps) step(t, pfa, pfb);
     if (!(a.dbg & 4)) finalize(nsteps - 1);
-    __syncthreads();
+    wg_barrier();
   }
 };
 
