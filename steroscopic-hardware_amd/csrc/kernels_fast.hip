@@ -131,7 +131,9 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static constexpr int OL = P * ((H + P - 1) / P);  // first output column inside the tile
   static constexpr int STEP = TW - 2 * OL;          // output columns per tile
   static constexpr int B1 = 2 * H + 1;              // window width
-  static constexpr int NR = 2 * H + 3;              // ring rows (window + leaving row + prefetch)
+  static constexpr int RB = 1;                      // rows per barrier (a "super-step")
+  static constexpr int NB = 2 * RB;                 // row-best buffers: RB being filled + RB being drained
+  static constexpr int NR = 2 * H + 1 + 2 * RB;     // ring rows: window + leaving rows of a super-step + RB landing
   static constexpr int NRV = P + ND;                // R values a lane loads per row (last one unused)
 
   // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
@@ -216,9 +218,12 @@ struct Cw {                                         // P columns per lane: 4 (h 
 
   // Unpacked: the window sum is the key (bias trick).  Packed: the window sums of disparities
   // dbase+2q (low half) and dbase+2q+1 (high half) become two keys (SAD << 16) | d.
-  template <bool MASK>
+  // MASK: 0 = every candidate of the chunk is valid for every pixel; 1 = the chunk runs past
+  // MaxDisparity (wave-uniform: only the first qn candidates exist); 2 = per-pixel limits (the
+  // leftmost columns of the image, where d <= x-h cuts the range).
+  template <int MASK>
   static __device__ __forceinline__ void stage_b(const Pre& r, int q, const int (&jlim)[P], unsigned (&best)[P],
-                                                 unsigned dbase)
+                                                 unsigned dbase, int qn)
   {
     // window sum of column p = own columns + last (h-p) columns of the left lane + first (p+h-P+1)
     // columns of the right lane.  The DPP adds are issued as two sweeps over p (all "left" pulls,
@@ -242,33 +247,37 @@ struct Cw {                                         // P columns per lane: 4 (h 
       if constexpr (PK) {
         unsigned ke = (s[p] << 16) | (dbase + 2 * q);             // v_lshl_or_b32
         unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
-        if (MASK) {
+        if (MASK == 2) {
           ke = (2 * q > jlim[p]) ? KEY_INVALID : ke;
           ko = (2 * q + 1 > jlim[p]) ? KEY_INVALID : ko;
         }
+        if (MASK == 1 && 2 * q + 1 >= qn) ko = KEY_INVALID;       // wave-uniform: scalar branch
         const unsigned m = ke < ko ? ke : ko;
         best[p] = m < best[p] ? m : best[p];                      // v_min3_u32
       } else {
         unsigned k = s[p];
-        if (MASK) k = (q > jlim[p]) ? KEY_INVALID : k;            // d > min(D, x-h): not a candidate
+        if (MASK == 2) k = (q > jlim[p]) ? KEY_INVALID : k;       // d > min(D, x-h): not a candidate
         best[p] = k < best[p] ? k : best[p];
       }
     }
   }
 
-  template <bool MASK>
+  template <int MASK>
   static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][NC], const int (&jlim)[P],
-                                                    unsigned (&best)[P], unsigned dbase)
+                                                    unsigned (&best)[P], unsigned dbase, int qn)
   {
+    constexpr int CPR = PK ? 2 : 1;                            // candidates per accumulator register
     Pre cur, nxt;
     stage_a(C, 0, cur);
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-      if (q + 1 < NC) stage_a(C, q + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      stage_b<MASK>(cur, q, jlim, best, dbase);
-      __builtin_amdgcn_sched_barrier(0);
-      cur = nxt;
+      if (MASK != 1 || CPR * q < qn) {                         // else: the rest of the chunk does not exist
+        if (q + 1 < NC) stage_a(C, q + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_b<MASK>(cur, q, jlim, best, dbase, qn);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
     }
   }
 
@@ -284,8 +293,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int RW = TW + a.dpad + 1;                       // R values per ring row (multiple of 4)
     const int ROWW = TW + RW;                             // u32 per ring row: L[TW] then R[RW]
     unsigned* ring = smem;                                // (NR + 1) rows; row NR stays zero
-    unsigned* rowbest = smem + (NR + 1) * ROWW;           // [2][TW]
-    unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + 2 * TW);   // [maxdisp+1]
+    unsigned* rowbest = smem + (NR + 1) * ROWW;           // [NB][TW]
+    unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + NB * TW);  // [maxdisp+1]
 
     const int tile = blockIdx.x + a.tile0;
     const int tx = a.tx0 + tile * STEP;                   // image column of lane 0, p 0
@@ -303,7 +312,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
 
     // ---- one-time setup: zero row, row-best buffers, output LUT ------------------------------
     for (int i = tid; i < ROWW; i += nt) ring[NR * ROWW + i] = 0;
-    for (int i = tid; i < 2 * TW; i += nt) rowbest[i] = KEY_INVALID;
+    for (int i = tid; i < NB * TW; i += nt) rowbest[i] = KEY_INVALID;
     for (int i = tid; i <= j.maxdisp; i += nt)
       lut[i] = (unsigned char)(j.raw ? min(i, 255) : (i * 255) / j.maxdisp);     // sad.go:91-93
 
@@ -317,17 +326,21 @@ struct Cw {                                         // P columns per lane: 4 (h 
       const uint8_t* base = isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride;
       return (unsigned)base[col];
     };
-    {                                                     // first window row resident before the loop
-      unsigned* dst = ring;                               // row ys-H lives in slot 0
-      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(ys - H, i) << a.pixshift;
+    // Step t handles the entering row ys-H+t, which lives in ring slot t % NR.  RB steps form a
+    // super-step with ONE barrier (a barrier per row cost 28 % in tools/ubench/block_bench.hip:
+    // six waves on four SIMDs never finish a row together).
+    for (int k = 0; k < RB; ++k) {                        // rows of super-step 0 resident before the loop
+      unsigned* dst = ring + k * ROWW;
+      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(ys - H + k, i) << a.pixshift;
     }
     __syncthreads();
 
-    const int nsteps = (ye - ys) + 2 * H;                 // ring slots advance by one per step
+    const int nsteps = (ye - ys) + 2 * H;
     // Roles: waves [0, nw) compute; wave nw is the helper that streams rows into the ring and
     // turns finished row buffers into output, so the compute waves' loop is VALU + LDS reads only.
-    // Every wave executes exactly one barrier per step.
+    // Every wave executes exactly one barrier per super-step.
     if (wv == a.nw) {
+      if (a.dbg & 64) return;                             // tuning aid (with 16): no helper at all
       helper_loop(a, ring, rowbest, lut, Lg, Rg, Og, ROWW, nvals, tx, ys, nsteps, ox0, ox1, lane);
       return;
     }
@@ -337,52 +350,93 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const bool lane_valid = x0 < j.w;                     // (w - tx) % P == 0: all-or-nothing
     unsigned C[P][NC];
     int jlim[P];
+    // Candidates d > x-h do not exist near the left image edge (sad.go:66-69).  Instead of masking
+    // their keys in every row (which made the leftmost tile's workgroups the critical path of the
+    // whole launch), their column sums start with a penalty that outlives the sliding updates:
+    // a pixel's candidate d is missing exactly when its window's first column c0 = x-h is < d.
+    //   unpacked: every column c < d starts at 2^27 (17 columns * 2^27 + any key < 2^32);
+    //   packed:   u16 sums cannot hold more than one penalty per window, so only columns
+    //             c < d with c == d-1 (mod 2h+1) start at PEN = (2h+1)^2*255: every full window
+    //             holds exactly one column of that class, and it is < d iff c0 < d; a penalised sum
+    //             is >= the worst d = 0 sum and <= 2*PEN, which fits 16 bits for h <= 5.
+    // Windows clipped on the left (x <= h) only have d = 0 and are forced to lut[0] by the helper;
+    // windows clipped on the right can meet missing candidates only when w <= D + 2h + 1: those
+    // frames, and packed h = 6, 7, keep the per-key masks (reduce_row<2>).
+    constexpr bool PEN_OK = !PK || H <= 5;
+    constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
+    const bool use_pen = PEN_OK && (!PK || j.w > j.maxdisp + B1 + 1) && !(a.dbg & 256);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int col = x0 + p;
       const bool biased = !PK && ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
       jlim[p] = min(j.maxdisp, max(0, col - H)) - dc;     // candidate q valid iff q <= jlim[p]
 #pragma unroll
-      for (int q = 0; q < NC; ++q) C[p][q] = biased ? (unsigned)(dc + q) : 0u;
+      for (int q = 0; q < NC; ++q) {
+        if constexpr (PK) {
+          unsigned v = 0u;
+          if (use_pen && col >= 0) {
+            const int de = dc + 2 * q, dd = dc + 2 * q + 1;
+            if (col < de && (de - 1 - col) % B1 == 0) v |= PEN;
+            if (col < dd && (dd - 1 - col) % B1 == 0) v |= PEN << 16;
+          }
+          C[p][q] = v;
+        } else {
+          unsigned v = biased ? (unsigned)(dc + q) : 0u;
+          if (use_pen && col >= 0 && col < dc + q) v += PEN;
+          C[p][q] = v;
+        }
+      }
     }
-    // is any (pixel, d) of this wave outside the candidate range?  (wave-uniform)
-    const bool need_mask = (dc + ND - 1 > j.maxdisp) || (max(ox0, 0) - H < dc + ND - 1);
+    // which candidates of this wave's chunk exist?  (all three are wave-uniform)
+    const int qn = min(ND, j.maxdisp - dc + 1);           // chunk runs past MaxDisparity: first qn only
+    const bool tail_mask = qn < ND;
+    const bool lane_mask = !use_pen && !(a.dbg & 128) &&
+                           max(ox0, 0) - H < min(dc + ND - 1, j.maxdisp);   // some pixel has d <= x-h < chunk end
 
     // this lane's operands inside a ring row (u32 index): L at lofs, R value m at rofs + m
     const int lofs = P * lane;
     const int rofs = TW + (a.dpad - dc - (ND - 1)) + P * lane;        // multiple of 4 by construction
 
     int slot_in = 0;                                      // row ys-H+t lives in slot t % NR
-    for (int t = 0; t < nsteps; ++t) {
-      // the leaving row sits NR-B1 = 2 slots ahead; before the window is full: the zero row
-      const int slot_out = t > 2 * H ? (slot_in + 2 >= NR ? slot_in + 2 - NR : slot_in + 2) : NR;
-      const unsigned* rin = ring + slot_in * ROWW;
-      const unsigned* rout = ring + slot_out * ROWW;
-      if (lane_valid && !(a.dbg & 1))
-        update_columns(C, reinterpret_cast<const uint4*>(rin + lofs), reinterpret_cast<const uint4*>(rin + rofs),
-                       reinterpret_cast<const uint4*>(rout + lofs), reinterpret_cast<const uint4*>(rout + rofs));
+    for (int t0 = 0; t0 < nsteps; t0 += RB) {
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int t = t0 + k;
+        if (t < nsteps) {
+          // the leaving row (B1 rows earlier) sits NR-B1 = 2*RB slots ahead; before the window is
+          // full: the zero row
+          const int so = slot_in + 2 * RB;
+          const int slot_out = t > 2 * H ? (so >= NR ? so - NR : so) : NR;
+          const unsigned* rin = ring + slot_in * ROWW;
+          const unsigned* rout = ring + slot_out * ROWW;
+          if (lane_valid && !(a.dbg & 1))
+            update_columns(C, reinterpret_cast<const uint4*>(rin + lofs), reinterpret_cast<const uint4*>(rin + rofs),
+                           reinterpret_cast<const uint4*>(rout + lofs), reinterpret_cast<const uint4*>(rout + rofs));
 
-      if (t >= 2 * H && !(a.dbg & 2)) {
-        unsigned best[P];
+          if (t >= 2 * H && !(a.dbg & 2)) {
+            unsigned best[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
-        if (need_mask) {
+            for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
+            if (lane_mask) {
 #pragma unroll
-          for (int p = 0; p < P; ++p) asm volatile("" : "+v"(jlim[p]));   // keep the compares in the loop
-          reduce_row<true>(C, jlim, best, (unsigned)dc);
-        } else {
-          reduce_row<false>(C, jlim, best, (unsigned)dc);
+              for (int p = 0; p < P; ++p) asm volatile("" : "+v"(jlim[p]));   // keep the compares in the loop
+              reduce_row<2>(C, jlim, best, (unsigned)dc, qn);
+            } else if (tail_mask) {
+              reduce_row<1>(C, jlim, best, (unsigned)dc, qn);
+            } else {
+              reduce_row<0>(C, jlim, best, (unsigned)dc, qn);
+            }
+            unsigned* rb = rowbest + (t % NB) * TW + lofs;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+              if (!(a.dbg & 32)) atomicMin(rb + p, best[p]);                  // ds_min_u32
+              else asm volatile("" :: "v"(best[p]));
+          }
+          slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
         }
-        unsigned* rb = rowbest + (t & 1) * TW + lofs;
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-          if (!(a.dbg & 32)) atomicMin(rb + p, best[p]);                  // ds_min_u32
-          else asm volatile("" :: "v"(best[p]));
       }
       if (!(a.dbg & 16)) wg_barrier();
-      slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
     }
-    wg_barrier();                                         // pairs with the helper's final barrier
   }
 
   // ---- helper wave: row streaming + output --------------------------------------------------------
@@ -421,54 +475,72 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const unsigned kmask = (1u << a.ksh) - 1u;
     auto finalize = [&](int t) {                          // output row of step t: 4 pixels per lane per pass
       const int y = ys + t - 2 * H;
-      uint4* rb = reinterpret_cast<uint4*>(rowbest + (t & 1) * TW);
+      uint4* rb = reinterpret_cast<uint4*>(rowbest + (t % NB) * TW);
       uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride - j.ox;
 #pragma unroll
       for (int g = 0; g < TW / 256; ++g) {
         const int i = 4 * (lane + 64 * g);
         const uint4 k = rb[lane + 64 * g];
         rb[lane + 64 * g] = make_uint4(KEY_INVALID, KEY_INVALID, KEY_INVALID, KEY_INVALID);
-        const unsigned char v0 = lut[k.x & kmask], v1 = lut[k.y & kmask], v2 = lut[k.z & kmask], v3 = lut[k.w & kmask];
+        unsigned char v0 = lut[k.x & kmask], v1 = lut[k.y & kmask], v2 = lut[k.z & kmask], v3 = lut[k.w & kmask];
         const int x = tx + i;
+        if (x <= H) {                                       // x <= h: d = 0 is the only candidate (sad.go:66-69)
+          v0 = lut[0];
+          if (x + 1 <= H) v1 = lut[0];
+          if (x + 2 <= H) v2 = lut[0];
+          if (x + 3 <= H) v3 = lut[0];
+        }
         if (x >= ox0 && x < ox1) orow[x] = v0;
         if (x + 1 >= ox0 && x + 1 < ox1) orow[x + 1] = v1;
         if (x + 2 >= ox0 && x + 2 < ox1) orow[x + 2] = v2;
         if (x + 3 >= ox0 && x + 3 < ox1) orow[x + 3] = v3;
       }
     };
-    // two register sets alternate (loop unrolled by two) so that a row's loads are only waited
-    // for one full step after they were issued
-    unsigned pfa[MAXV], pfb[MAXV];
-    load_row(ys - H + 1, pfa);                            // row that step 0 lands
-    int slot_next = 1 == NR ? 0 : 1;
-    // Order inside a step matters: hipcc cannot count the conditional loads / stores below, so its
-    // wait before the first use of land[] is vmcnt(0).  Landing first makes that wait cover only
-    // operations issued a whole step earlier (long complete); the loads and stores issued after it
-    // are not waited for until the next step.
-    auto step = [&](int t, unsigned (&land)[MAXV], unsigned (&fill)[MAXV]) {
-      if (t + 1 < nsteps) {
-        unsigned* dst = ring + slot_next * ROWW;
+    // Super-step s (steps t0 = s*RB .. t0+RB-1, between barrier s-1 and barrier s):
+    //   land   the rows of super-step s+1 (loaded during super-step s-1) into their ring slots,
+    //   load   the rows of super-step s+2 into the other register set,
+    //   drain  the row buffers of super-step s-1 (complete since barrier s-1) to the output.
+    // Order matters: hipcc cannot count the conditional loads / stores, so its wait before the
+    // first use of a landed register is vmcnt(0); landing first makes that wait cover only
+    // operations issued a whole super-step earlier.
+    unsigned pfa[RB][MAXV], pfb[RB][MAXV];
 #pragma unroll
-        for (int v = 0; v < MAXV; ++v) {
-          const int i = lane + 64 * v;
-          if (i < nvals) dst[i] = land[v] << a.pixshift;
+    for (int k = 0; k < RB; ++k) load_row(ys - H + RB + k, pfa[k]);       // rows of super-step 1
+    auto sstep = [&](int t0, unsigned (&land)[RB][MAXV], unsigned (&fill)[RB][MAXV]) {
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int t = t0 + RB + k;                        // step whose row is landed now
+        if (t < nsteps) {
+          unsigned* dst = ring + (t % NR) * ROWW;
+#pragma unroll
+          for (int v = 0; v < MAXV; ++v) {
+            const int i = lane + 64 * v;
+            if (i < nvals) dst[i] = land[k][v] << a.pixshift;
+          }
         }
       }
-      if (t + 2 < nsteps) load_row(ys - H + t + 2, fill); // two rows ahead
-      if (t > 2 * H && !(a.dbg & 4)) finalize(t - 1);
+#pragma unroll
+      for (int k = 0; k < RB; ++k)
+        if (t0 + 2 * RB + k < nsteps) load_row(ys - H + t0 + 2 * RB + k, fill[k]);
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int t = t0 - RB + k;                        // step whose output row is drained now
+        if (t >= 2 * H && !(a.dbg & 4)) finalize(t);
+      }
       if (!(a.dbg & 16)) wg_barrier();
-      slot_next = slot_next + 1 == NR ? 0 : slot_next + 1;
     };
-    int t = 0;
-    for (; t + 1 < nsteps; t += 2) {
-      step(t, pfa, pfb);
-      step(t + 1, pfb, pfa);
+    int t0 = 0;
+    for (; t0 + RB < nsteps; t0 += 2 * RB) {
+      sstep(t0, pfa, pfb);
+      sstep(t0 + RB, pfb, pfa);
     }
-    if (t < nsteps) step(t, pfa, pfb);
-    if (!(a.dbg & 4)) finalize(nsteps - 1);
-    wg_barrier();
+    if (t0 < nsteps) { sstep(t0, pfa, pfb); t0 += RB; }
+    // rows of the last super-step (complete since the last barrier)
+    for (int t = t0 - RB; t < nsteps; ++t)
+      if (t >= 2 * H && !(a.dbg & 4)) finalize(t);
   }
 };
+
 
 // WB = workgroup-size bound: 1024 threads -> 128 VGPRs.  The unpacked P = 8 kernel keeps 96 column
 // sums: 512 threads (256 VGPRs, no spills) when the workgroup fits, else 768 (168 VGPRs).
@@ -542,7 +614,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
   const int ROWW = 2 * K::TW + a.dpad + 1;
-  const size_t lds = (size_t)((K::NR + 1) * ROWW + 2 * K::TW) * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
+  const size_t lds = (size_t)((K::NR + 1) * ROWW + K::NB * K::TW) * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
                      + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     CwArgs aa = a;

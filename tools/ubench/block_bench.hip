@@ -14,12 +14,23 @@ __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
   extern __shared__ __attribute__((aligned(16))) unsigned smem[];
   unsigned C[P][NC]; int jlim[P]; unsigned best[P];
   for (int p = 0; p < P; ++p) { jlim[p] = 100; best[p] = 0xffffffffu; for (int q = 0; q < NC; ++q) C[p][q] = io[(threadIdx.x * P + p) * NC + q] & 0xff00ff; }
-  for (int i = threadIdx.x; i < 4096; i += blockDim.x) smem[i] = io[i] & 0xffff;
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) smem[i] = io[i] & 0xff;
   __syncthreads();
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint4* l = reinterpret_cast<const uint4*>(smem + 4 * (threadIdx.x & 63));
-  const uint4* r = reinterpret_cast<const uint4*>(smem + 1024 + 4 * (threadIdx.x & 63));
+  const uint4* r = reinterpret_cast<const uint4*>(smem + 256 + 12 * wv + 4 * (threadIdx.x & 63));
+  int slot = 0;
   for (int it = 0; it < iters; ++it) {
-    if (MODE & 1) K::update_columns(C, l, r, l + 64, r + 64);
+    const int so = (MODE & 128) ? slot * 146 : 0;                    // ring rows of 584 dwords = 146 uint4
+    const int so2 = (MODE & 128) ? ((slot + 2) % 11) * 146 : 64;
+    if (MODE & 1) K::update_columns(C, l + so, r + so, l + so2, r + so2);
+    slot = slot + 1 == 11 ? 0 : slot + 1;
+    if (MODE & 32) { for (int p = 0; p < P; ++p) for (int q = 0; q < NC; ++q) C[p][q] += (unsigned)it & 1u; }   // defeat hoisting
+    if (MODE & 2) K::template reduce_row<0>(C, jlim, best, 0u, ND);
+    if (MODE & 4) K::template reduce_row<2>(C, jlim, best, 0u, ND);
+    if (MODE & 2 || MODE & 4) { for (int p = 0; p < P; ++p) best[p] |= 0x80000000u; }   // keep the min chain from saturating
+    if (MODE & 256) { unsigned* rb = smem + 7000 + (it & 1) * 256 + 4 * (threadIdx.x & 63); for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]); }
+    if (MODE & 64) __syncthreads();
     C[0][0] += best[0] & 1;      // keep a dependency so nothing is hoisted
   }
   unsigned acc = 0;
@@ -49,13 +60,14 @@ void run(const char* name, int nw, int wgs_per_cu)
 
 int main()
 {
-  run<4, 24, 4, 32, true>("packed P4 ND24 perturb only", 3, 4);
-  run<4, 24, 4, 34, true>("packed P4 ND24 perturb+reduce", 3, 4);
-  run<4, 24, 4, 36, true>("packed P4 ND24 perturb+reduce(mask)", 3, 4);
-  run<4, 24, 4, 35, true>("packed P4 ND24 perturb+update+reduce", 3, 4);
-  run<4, 12, 4, 32, true>("packed P4 ND12 perturb only", 6, 4);
-  run<4, 12, 4, 34, true>("packed P4 ND12 perturb+reduce", 6, 4);
-  run<4, 12, 4, 32, false>("unpacked P4 ND12 perturb only", 6, 2);
-  run<4, 12, 4, 34, false>("unpacked P4 ND12 perturb+reduce", 6, 2);
+  run<4, 12, 4, 2 + 32, true>("pk ND12 red nomask", 6, 4);
+  run<4, 12, 4, 4 + 32, true>("pk ND12 red lanemask", 6, 4);
+  run<4, 12, 4, 3, true>("pk ND12 upd+red", 6, 4);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier", 6, 4);
+  run<4, 12, 4, 3 + 128, true>("pk ND12 upd+red +ring", 6, 4);
+  run<4, 12, 4, 3 + 256, true>("pk ND12 upd+red +ds_min", 6, 4);
+  run<4, 12, 4, 3 + 64 + 128 + 256, true>("pk ND12 upd+red +all", 6, 4);
+  run<4, 12, 4, 3 + 64 + 128 + 256, true>("pk ND12 upd+red +all", 7, 4);
+  run<4, 12, 4, 3 + 64 + 128 + 256, true>("pk ND12 upd+red +all", 6, 2);
   return 0;
 }
