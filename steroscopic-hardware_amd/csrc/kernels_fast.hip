@@ -9,9 +9,13 @@
 //     wave-instruction, plain v_add/v_sub ~2.5, v_qsad_pk_u16_u8 is quarter rate; one LDS dword per
 //     lane costs as much as two such VALU ops.  So: every |L-R| is one SAD instruction with the
 //     accumulate folded in, everything else is adds/subs, operands stay in registers.
-//   * lane l of a wave owns P (4 or 8) adjacent columns; a compute wave owns ND consecutive
-//     disparities for its 64*P columns; the NW compute waves of a workgroup split the disparity
-//     range of one tile; one more wave (the helper) streams rows and writes output.
+//   * lane l of a wave owns P (4 or 8) adjacent columns; a wave owns ND consecutive disparities
+//     for its 64*P columns; the NW waves of a workgroup split the disparity range of one tile.
+//     NW is a multiple of 4 with equal work per wave whenever D allows: the four SIMDs of a CU
+//     issue oldest-workgroup-first, so a workgroup whose waves sit 2,2,1,1 on them runs at the pace
+//     of the doubly loaded SIMDs and a quarter of the CU idles (tools/ubench/block_bench.hip:
+//     6 waves per workgroup cost 1.29x, 4 / 8 / 12 cost 1.00x).  The UI's disparity ranges are
+//     multiples of 16, i.e. 16k+1 candidates: the last wave carries the odd one out.
 //   * vertical: each lane keeps the column sums of its (column, disparity) pairs in registers and
 //     slides them down the strip: + |L-R| of the row entering the window, - |L-R| of the row
 //     leaving it.  Packed variant (window SAD < 65536): two adjacent disparities share a register
@@ -22,10 +26,14 @@
 //     (v_min3_u32).  Packed: v_lshl_or_b32 / v_perm_b32 build the two keys of a register.
 //     Unpacked: pixels are pre-scaled by 2^KSH and every window contains exactly one column whose
 //     sum starts at d, so the window sum IS the key.
-//   * compute waves merge their per-pixel minima with ds_min_u32 into a row buffer in LDS; after
-//     the one barrier per row the helper wave maps key -> d -> best*255/D (LUT) and stores u8.
-//   * image rows stream through an LDS ring (2h+3 rows, one u32 per pixel), loaded by the helper
-//     two rows ahead.  ND is a multiple of 4 and the R part of a ring row is offset so that every
+//   * waves merge their per-pixel minima with ds_min_u32 into a row buffer in LDS; after the one
+//     barrier per row every wave maps its 1/NW share of the keys -> d -> best*255/D (LUT) and
+//     stores u8.
+//   * image rows stream through an LDS ring (2h+3 rows, one u32 per pixel); every wave loads its
+//     1/NW share of the next row before its arithmetic and lands it in the ring afterwards, so the
+//     load latency hides behind a whole row of VALU work and all waves stay symmetric (a dedicated
+//     streaming wave made one SIMD the pacemaker, see above).
+//     ND is a multiple of 4 and the R part of a ring row is offset so that every
 //     lane's operands are 16-byte aligned: all operand reads are ds_read_b128, bank-conflict free
 //     at a lane stride of 16 bytes (ds_read_b32 at that stride was a 4-way conflict: 72 % of LDS
 //     cycles in the first version).
@@ -38,14 +46,16 @@ namespace {
 
 struct CwArgs {
   Job j;
-  int nw;          // waves per workgroup (disparity chunks)
+  int nw;          // waves per workgroup (disparity chunks), 4..16
+  int xw;          // wave that also owns candidate nw*ND (the 16k+1-th), or -1
   int ksh;         // bits of the disparity field of a key (unpacked: 2^ksh > maxdisp; packed: 16)
   int pixshift;    // left shift applied to pixels landing in LDS (unpacked: ksh; packed: 0)
-  int dpad;        // columns of R kept left of the tile: nw*ND - 1 (== 3 mod 4)
+  int dpad;        // columns of R kept left of the tile (== 3 mod 4, >= largest candidate)
   int tx0;         // origin of tile 0 (<= 0, == w mod P)
   int tile0;       // first tile index launched (blockIdx.x + tile0)
   int th;          // output rows per strip
-  int dbg;         // tuning aid (SADHIP_TUNE_DBG): 1 skip column update, 2 skip row reduce, 4 skip finalize, 8 skip prefetch
+  int shl, shr;    // per-wave share of a ring row: L elements (= output pixels), R elements
+  int nomask_pen;  // tuning aid: 1 = never use the penalty initialisation (per-key masks instead)
 };
 
 constexpr unsigned KEY_INVALID = 0xffffffffu;
@@ -74,6 +84,23 @@ __device__ __forceinline__ void sad_sub4(unsigned& c0, unsigned& c1, unsigned& c
       "v_sub_u32 %3, %3, %7"
       : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
       : "v"(l), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
+}
+// c_i -= |l_i - r_i| for four columns of one disparity.
+__device__ __forceinline__ void sad_sub4x(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
+                                          unsigned l0, unsigned l1, unsigned l2, unsigned l3,
+                                          unsigned r0, unsigned r1, unsigned r2, unsigned r3)
+{
+  unsigned t0, t1, t2, t3;
+  asm("v_sad_u32 %4, %8, %12, 0\n\t"
+      "v_sad_u32 %5, %9, %13, 0\n\t"
+      "v_sad_u32 %6, %10, %14, 0\n\t"
+      "v_sad_u32 %7, %11, %15, 0\n\t"
+      "v_sub_u32 %0, %0, %4\n\t"
+      "v_sub_u32 %1, %1, %5\n\t"
+      "v_sub_u32 %2, %2, %6\n\t"
+      "v_sub_u32 %3, %3, %7"
+      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
 }
 // ---- packed variant: one register holds the column sums of two adjacent disparities as u16 halves.
 // Pixels in LDS are plain zero-extended bytes, so v_sad_u8 / v_sad_hi_u8 (|a-b| over 4 byte lanes,
@@ -110,10 +137,10 @@ __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane 
 }
 
 // Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also emits
-// s_waitcnt vmcnt(0): the helper wave would then sit at every row barrier until the global loads
-// it has just issued for a LATER row have returned (a full memory latency per row, with every
-// compute wave waiting behind it).  The loads are consumed a step later; hipcc places the
-// vmcnt wait at that use by itself.  "memory" keeps the compiler from moving LDS accesses across.
+// s_waitcnt vmcnt(0): every wave would then sit at every row barrier until the output bytes it has
+// just stored are acknowledged (a full memory round trip per row).  Nothing depends on them;
+// hipcc places the vmcnt wait of the row loads at their use by itself.  "memory" keeps the
+// compiler from moving LDS accesses across.
 __device__ __forceinline__ void wg_barrier()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -131,10 +158,11 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static constexpr int OL = P * ((H + P - 1) / P);  // first output column inside the tile
   static constexpr int STEP = TW - 2 * OL;          // output columns per tile
   static constexpr int B1 = 2 * H + 1;              // window width
-  static constexpr int RB = 1;                      // rows per barrier (a "super-step")
-  static constexpr int NB = 2 * RB;                 // row-best buffers: RB being filled + RB being drained
-  static constexpr int NR = 2 * H + 1 + 2 * RB;     // ring rows: window + leaving rows of a super-step + RB landing
+  static constexpr int NB = 2;                      // row-best buffers: one being filled, one being drained
+  static constexpr int NR = 2 * H + 3;              // ring rows: window + the leaving row + the landing row
   static constexpr int NRV = P + ND;                // R values a lane loads per row (last one unused)
+  static constexpr int MAXL = P / 4;                // ring-row L elements per lane (>= 4 waves share a row)
+  static constexpr int MAXR = (TW + 4 * ND + 4 + 255) / 256;   // ... R elements per lane
 
   // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
   // lin/lout: this lane's 4 L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
@@ -199,6 +227,48 @@ struct Cw {                                         // P columns per lane: 4 (h 
     }
   }
 
+  // The wave that owns the odd candidate dx = nw*ND (16k+1 candidates, see plan_for) slides its
+  // column sums here: lx/rx point at this lane's L pixels and at the 16-byte block holding R value
+  // x0 - dx - 3 (the lane's P values start at element 3).  Pixels are plain bytes (packed) or
+  // pre-shifted (unpacked): v_sad_u32 accumulates the right thing in both.
+  static __device__ __forceinline__ void extra_update(unsigned (&CX)[P][1], const uint4* lin, const uint4* rxin,
+                                                      const uint4* lout, const uint4* rxout)
+  {
+    {
+      unsigned li[P], ri[P + 4];
+#pragma unroll
+      for (int m = 0; m < P / 4; ++m) {
+        const uint4 l4 = lin[m];
+        li[4 * m] = l4.x; li[4 * m + 1] = l4.y; li[4 * m + 2] = l4.z; li[4 * m + 3] = l4.w;
+      }
+#pragma unroll
+      for (int m = 0; m < P / 4 + 1; ++m) {
+        const uint4 r4 = rxin[m];
+        ri[4 * m] = r4.x; ri[4 * m + 1] = r4.y; ri[4 * m + 2] = r4.z; ri[4 * m + 3] = r4.w;
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) sad_acc(CX[p][0], li[p], ri[p + 3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      unsigned lo[P], ro[P + 4];
+#pragma unroll
+      for (int m = 0; m < P / 4; ++m) {
+        const uint4 l4 = lout[m];
+        lo[4 * m] = l4.x; lo[4 * m + 1] = l4.y; lo[4 * m + 2] = l4.z; lo[4 * m + 3] = l4.w;
+      }
+#pragma unroll
+      for (int m = 0; m < P / 4 + 1; ++m) {
+        const uint4 r4 = rxout[m];
+        ro[4 * m] = r4.x; ro[4 * m + 1] = r4.y; ro[4 * m + 2] = r4.z; ro[4 * m + 3] = r4.w;
+      }
+#pragma unroll
+      for (int p = 0; p < P; p += 4)
+        sad_sub4x(CX[p][0], CX[p + 1][0], CX[p + 2][0], CX[p + 3][0], lo[p], lo[p + 1], lo[p + 2], lo[p + 3],
+                  ro[p + 3], ro[p + 4], ro[p + 5], ro[p + 6]);
+    }
+  }
+
   // ---- horizontal window sums + key minimum for one row --------------------------------------
   // Per disparity q: stage A = in-lane prefix sums ps[] and the suffix sums the right neighbour
   // needs; stage B = window sums (DPP adds pulling from both neighbour lanes) folded into best[].
@@ -207,7 +277,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // A(q+1) is issued between A(q) and B(q), pinned with sched_barrier.
   struct Pre { unsigned ps[P + 1]; unsigned suf[P + 1]; };   // suf[k] = sum of the lane's last k columns
 
-  static __device__ __forceinline__ void stage_a(const unsigned (&C)[P][NC], int q, Pre& r)
+  template <int W>
+  static __device__ __forceinline__ void stage_a(const unsigned (&C)[P][W], int q, Pre& r)
   {
     r.ps[0] = 0;
 #pragma unroll
@@ -262,17 +333,17 @@ struct Cw {                                         // P columns per lane: 4 (h 
     }
   }
 
-  template <int MASK>
-  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][NC], const int (&jlim)[P],
+  template <int MASK, int W>
+  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const int (&jlim)[P],
                                                     unsigned (&best)[P], unsigned dbase, int qn)
   {
     constexpr int CPR = PK ? 2 : 1;                            // candidates per accumulator register
     Pre cur, nxt;
     stage_a(C, 0, cur);
 #pragma unroll
-    for (int q = 0; q < NC; ++q) {
+    for (int q = 0; q < W; ++q) {
       if (MASK != 1 || CPR * q < qn) {                         // else: the rest of the chunk does not exist
-        if (q + 1 < NC) stage_a(C, q + 1, nxt);
+        if (q + 1 < W) stage_a(C, q + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
         stage_b<MASK>(cur, q, jlim, best, dbase, qn);
         __builtin_amdgcn_sched_barrier(0);
@@ -310,46 +381,90 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int ox1 = min(tx + OL + STEP, j.x1);
     if (ys >= ye || ox0 >= ox1) return;
 
-    // ---- one-time setup: zero row, row-best buffers, output LUT ------------------------------
+    // ---- one-time setup: zero row, row-best buffers, output LUT, first ring row ----------------
+    // Ring row of image row yy: L columns [tx, tx+TW) then R columns [tx-dpad, tx+TW), one u32 per
+    // pixel (shifted by ksh in the unpacked variant), zero outside the image.
     for (int i = tid; i < ROWW; i += nt) ring[NR * ROWW + i] = 0;
     for (int i = tid; i < NB * TW; i += nt) rowbest[i] = KEY_INVALID;
     for (int i = tid; i <= j.maxdisp; i += nt)
       lut[i] = (unsigned char)(j.raw ? min(i, 255) : (i * 255) / j.maxdisp);     // sad.go:91-93
-
-    // ---- ring rows: L columns [tx, tx+TW) then R columns [tx-dpad, tx+TW), u32 pixels shifted by
-    //      ksh, zero outside the image.
-    const int nvals = ROWW;
-    auto fetch = [&](int yy, int i) -> unsigned {         // element i of the ring row of image row yy
-      const bool isR = i >= TW;
-      const int col = isR ? tx - a.dpad + (i - TW) : tx + i;
-      if (yy < 0 || yy >= j.h || col < 0 || col >= j.w) return 0u;
-      const uint8_t* base = isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride;
-      return (unsigned)base[col];
-    };
-    // Step t handles the entering row ys-H+t, which lives in ring slot t % NR.  RB steps form a
-    // super-step with ONE barrier (a barrier per row cost 28 % in tools/ubench/block_bench.hip:
-    // six waves on four SIMDs never finish a row together).
-    for (int k = 0; k < RB; ++k) {                        // rows of super-step 0 resident before the loop
-      unsigned* dst = ring + k * ROWW;
-      for (int i = tid; i < nvals; i += nt) dst[i] = fetch(ys - H + k, i) << a.pixshift;
+    {
+      const int yy = ys - H;                              // step 0's entering row -> slot 0
+      for (int i = tid; i < ROWW; i += nt) {
+        const bool isR = i >= TW;
+        const int col = isR ? tx - a.dpad + (i - TW) : tx + i;
+        unsigned v = 0u;
+        if (yy >= 0 && yy < j.h && col >= 0 && col < j.w)
+          v = (unsigned)(isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride)[col];
+        ring[i] = v << a.pixshift;
+      }
     }
     __syncthreads();
 
-    const int nsteps = (ye - ys) + 2 * H;
-    // Roles: waves [0, nw) compute; wave nw is the helper that streams rows into the ring and
-    // turns finished row buffers into output, so the compute waves' loop is VALU + LDS reads only.
-    // Every wave executes exactly one barrier per super-step.
-    if (wv == a.nw) {
-      if (a.dbg & 64) return;                             // tuning aid (with 16): no helper at all
-      helper_loop(a, ring, rowbest, lut, Lg, Rg, Og, ROWW, nvals, tx, ys, nsteps, ox0, ox1, lane);
-      return;
+    // ---- this wave's share of the row streaming and of the output -------------------------------
+    // L elements (= output pixels) [wv*shl, (wv+1)*shl), R elements [wv*shr, (wv+1)*shr); lane l
+    // takes elements l, l+64, ...  col >= 0: image column to load; -1: outside the image (zero);
+    // -2: not this lane's element.
+    const int il0 = wv * a.shl + lane, ir0 = wv * a.shr + lane;
+    int lcol[MAXL], rcol[MAXR];
+#pragma unroll
+    for (int v = 0; v < MAXL; ++v) {
+      const int i = il0 + 64 * v, col = tx + i;
+      lcol[v] = (lane + 64 * v < a.shl && i < TW) ? ((col >= 0 && col < j.w) ? col : -1) : -2;
     }
+#pragma unroll
+    for (int v = 0; v < MAXR; ++v) {
+      const int i = ir0 + 64 * v, col = tx - a.dpad + i;
+      rcol[v] = (lane + 64 * v < a.shr && i < RW) ? ((col >= 0 && col < j.w) ? col : -1) : -2;
+    }
+    unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
+    auto load_row = [&](int yy) {
+      if (yy >= 0 && yy < j.h) {
+        const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * j.lstride;
+        const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * j.rstride;
+#pragma unroll
+        for (int v = 0; v < MAXL; ++v) pfl[v] = lcol[v] >= 0 ? (unsigned)lrow[lcol[v]] : 0u;
+#pragma unroll
+        for (int v = 0; v < MAXR; ++v) pfr[v] = rcol[v] >= 0 ? (unsigned)rrow[rcol[v]] : 0u;
+      } else {
+#pragma unroll
+        for (int v = 0; v < MAXL; ++v) pfl[v] = 0u;
+#pragma unroll
+        for (int v = 0; v < MAXR; ++v) pfr[v] = 0u;
+      }
+    };
+    auto land_row = [&](unsigned* dst) {
+#pragma unroll
+      for (int v = 0; v < MAXL; ++v)
+        if (lcol[v] != -2) dst[il0 + 64 * v] = pfl[v] << a.pixshift;
+#pragma unroll
+      for (int v = 0; v < MAXR; ++v)
+        if (rcol[v] != -2) dst[TW + ir0 + 64 * v] = pfr[v] << a.pixshift;
+    };
+    const unsigned kmask = (1u << a.ksh) - 1u;
+    auto finalize = [&](int t) {                          // output row of step t, this wave's pixels
+      const int y = ys + t - 2 * H;
+      unsigned* rb = rowbest + (t & 1) * TW;
+      uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride - j.ox;
+#pragma unroll
+      for (int v = 0; v < MAXL; ++v) {
+        if (lcol[v] != -2) {
+          const int i = il0 + 64 * v, x = tx + i;
+          const unsigned k = rb[i];
+          rb[i] = KEY_INVALID;
+          // x <= h: d = 0 is the only candidate (sad.go:66-69)
+          const unsigned d = x <= H ? 0u : min(k & kmask, (unsigned)j.maxdisp);
+          const unsigned char o = lut[d];
+          if (x >= ox0 && x < ox1) orow[x] = o;
+        }
+      }
+    };
 
-    // ---- per-lane state of a compute wave ------------------------------------------------------
+    // ---- per-lane state ------------------------------------------------------------------------
     const int x0 = tx + P * lane;                         // first column of this lane
     const bool lane_valid = x0 < j.w;                     // (w - tx) % P == 0: all-or-nothing
-    unsigned C[P][NC];
-    int jlim[P];
+    const bool xtra = wv == a.xw;                         // this wave also owns candidate dx = nw*ND
+    const int dx = a.nw * ND;
     // Candidates d > x-h do not exist near the left image edge (sad.go:66-69).  Instead of masking
     // their keys in every row (which made the leftmost tile's workgroups the critical path of the
     // whole launch), their column sums start with a penalty that outlives the sliding updates:
@@ -359,195 +474,115 @@ struct Cw {                                         // P columns per lane: 4 (h 
     //             c < d with c == d-1 (mod 2h+1) start at PEN = (2h+1)^2*255: every full window
     //             holds exactly one column of that class, and it is < d iff c0 < d; a penalised sum
     //             is >= the worst d = 0 sum and <= 2*PEN, which fits 16 bits for h <= 5.
-    // Windows clipped on the left (x <= h) only have d = 0 and are forced to lut[0] by the helper;
+    // Windows clipped on the left (x <= h) only have d = 0 and are forced to lut[0] at the output;
     // windows clipped on the right can meet missing candidates only when w <= D + 2h + 1: those
     // frames, and packed h = 6, 7, keep the per-key masks (reduce_row<2>).
     constexpr bool PEN_OK = !PK || H <= 5;
     constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
-    const bool use_pen = PEN_OK && (!PK || j.w > j.maxdisp + B1 + 1) && !(a.dbg & 256);
+    const bool use_pen = PEN_OK && (!PK || j.w > j.maxdisp + B1 + 1) && !a.nomask_pen;
+    auto init_sum = [&](int col, int d) -> unsigned {     // start value of the column sum of (col, d)
+      if constexpr (PK) {
+        return (use_pen && col >= 0 && col < d && (d - 1 - col) % B1 == 0) ? PEN : 0u;
+      } else {
+        const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
+        return (biased ? (unsigned)d : 0u) + ((use_pen && col >= 0 && col < d) ? PEN : 0u);
+      }
+    };
+    unsigned C[P][NC], CX[P][1];
+    int jlim[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int col = x0 + p;
-      const bool biased = !PK && ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
       jlim[p] = min(j.maxdisp, max(0, col - H)) - dc;     // candidate q valid iff q <= jlim[p]
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
-        if constexpr (PK) {
-          unsigned v = 0u;
-          if (use_pen && col >= 0) {
-            const int de = dc + 2 * q, dd = dc + 2 * q + 1;
-            if (col < de && (de - 1 - col) % B1 == 0) v |= PEN;
-            if (col < dd && (dd - 1 - col) % B1 == 0) v |= PEN << 16;
-          }
-          C[p][q] = v;
-        } else {
-          unsigned v = biased ? (unsigned)(dc + q) : 0u;
-          if (use_pen && col >= 0 && col < dc + q) v += PEN;
-          C[p][q] = v;
-        }
+        if constexpr (PK) C[p][q] = init_sum(col, dc + 2 * q) | (init_sum(col, dc + 2 * q + 1) << 16);
+        else C[p][q] = init_sum(col, dc + q);
       }
+      CX[p][0] = init_sum(col, dx);
     }
-    // which candidates of this wave's chunk exist?  (all three are wave-uniform)
+    // which candidates of this wave's chunk exist?  (all wave-uniform)
     const int qn = min(ND, j.maxdisp - dc + 1);           // chunk runs past MaxDisparity: first qn only
     const bool tail_mask = qn < ND;
-    const bool lane_mask = !use_pen && !(a.dbg & 128) &&
-                           max(ox0, 0) - H < min(dc + ND - 1, j.maxdisp);   // some pixel has d <= x-h < chunk end
+    const bool lane_mask = !use_pen && max(ox0, 0) - H < min(dc + ND - 1 + (xtra ? 1 : 0), j.maxdisp);
 
     // this lane's operands inside a ring row (u32 index): L at lofs, R value m at rofs + m
     const int lofs = P * lane;
     const int rofs = TW + (a.dpad - dc - (ND - 1)) + P * lane;        // multiple of 4 by construction
+    const int rxofs = TW + (a.dpad - dx - 3) + P * lane;              // extra candidate: R value of column p at +3+p
 
-    int slot_in = 0;                                      // row ys-H+t lives in slot t % NR
-    for (int t0 = 0; t0 < nsteps; t0 += RB) {
+    // ---- main loop: step t brings in image row ys-H+t (ring slot t % NR) ------------------------
+    //   load    this wave's share of row t+1 (global -> registers; lands after the arithmetic)
+    //   update  column sums: + row t, - row t-(2h+1)
+    //   reduce  window sums -> per-pixel minimum of this wave's candidates -> ds_min into row buffer t&1
+    //   land    row t+1 in the slot of the row that left the window one step ago
+    //   output  this wave's pixels of row buffer (t-1)&1 (complete since the last barrier)
+    //   barrier
+    const int nsteps = (ye - ys) + 2 * H;
+    int slot_in = 0;
+    for (int t = 0; t < nsteps; ++t) {
+      if (t + 1 < nsteps) load_row(ys - H + t + 1);
+      const int so = slot_in + 2;                         // row t-(2h+1): NR - (2h+1) = 2 slots ahead
+      const int slot_out = t > 2 * H ? (so >= NR ? so - NR : so) : NR;   // window not full yet: zero row
+      const int sn = slot_in + 1 == NR ? 0 : slot_in + 1;
+      const unsigned* rin = ring + slot_in * ROWW;
+      const unsigned* rout = ring + slot_out * ROWW;
+      const uint4* lin4 = reinterpret_cast<const uint4*>(rin + lofs);
+      const uint4* rin4 = reinterpret_cast<const uint4*>(rin + rofs);
+      const uint4* lout4 = reinterpret_cast<const uint4*>(rout + lofs);
+      const uint4* rout4 = reinterpret_cast<const uint4*>(rout + rofs);
+      unsigned best[P];
 #pragma unroll
-      for (int k = 0; k < RB; ++k) {
-        const int t = t0 + k;
-        if (t < nsteps) {
-          // the leaving row (B1 rows earlier) sits NR-B1 = 2*RB slots ahead; before the window is
-          // full: the zero row
-          const int so = slot_in + 2 * RB;
-          const int slot_out = t > 2 * H ? (so >= NR ? so - NR : so) : NR;
-          const unsigned* rin = ring + slot_in * ROWW;
-          const unsigned* rout = ring + slot_out * ROWW;
-          if (lane_valid && !(a.dbg & 1))
-            update_columns(C, reinterpret_cast<const uint4*>(rin + lofs), reinterpret_cast<const uint4*>(rin + rofs),
-                           reinterpret_cast<const uint4*>(rout + lofs), reinterpret_cast<const uint4*>(rout + rofs));
-
-          if (t >= 2 * H && !(a.dbg & 2)) {
-            unsigned best[P];
+      for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
+      const bool out_row = t >= 2 * H;
+      if (lane_valid) update_columns(C, lin4, rin4, lout4, rout4);
+      if (out_row) {
+        if (lane_mask) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
-            if (lane_mask) {
-#pragma unroll
-              for (int p = 0; p < P; ++p) asm volatile("" : "+v"(jlim[p]));   // keep the compares in the loop
-              reduce_row<2>(C, jlim, best, (unsigned)dc, qn);
-            } else if (tail_mask) {
-              reduce_row<1>(C, jlim, best, (unsigned)dc, qn);
-            } else {
-              reduce_row<0>(C, jlim, best, (unsigned)dc, qn);
-            }
-            unsigned* rb = rowbest + (t % NB) * TW + lofs;
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-              if (!(a.dbg & 32)) atomicMin(rb + p, best[p]);                  // ds_min_u32
-              else asm volatile("" :: "v"(best[p]));
-          }
-          slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
+          for (int p = 0; p < P; ++p) asm volatile("" : "+v"(jlim[p]));   // keep the compares in the loop
+          reduce_row<2>(C, jlim, best, (unsigned)dc, qn);
+        } else if (tail_mask) {
+          reduce_row<1>(C, jlim, best, (unsigned)dc, qn);
+        } else {
+          reduce_row<0>(C, jlim, best, (unsigned)dc, qn);
         }
       }
-      if (!(a.dbg & 16)) wg_barrier();
-    }
-  }
-
-  // ---- helper wave: row streaming + output --------------------------------------------------------
-  // Step t (between barrier t-1 and barrier t): issue the global loads of row ys-H+t+2 (two rows
-  // ahead, so their latency spans a whole step), finalize the output row of step t-1 from its
-  // (now complete) row buffer and reset it, then land row ys-H+t+1 (loaded during step t-1) in the
-  // ring slot that held the row which left the window two steps ago.
-  static __device__ __forceinline__ void helper_loop(const CwArgs& a, unsigned* ring, unsigned* rowbest,
-                                                  const unsigned char* lut,
-                                                  const uint8_t* __restrict__ Lg, const uint8_t* __restrict__ Rg,
-                                                  uint8_t* __restrict__ Og, int ROWW, int nvals, int tx, int ys,
-                                                  int nsteps, int ox0, int ox1, int lane)
-  {
-    const Job& j = a.j;
-    constexpr int MAXV = (2 * TW + 15 * ND + 63) / 64;   // ring-row elements per helper lane (15 waves worst case)
-    int pcol[MAXV];                                       // image column, or -1: always zero
-    const int nL = TW;
+      if (xtra) {                                         // the odd candidate dx (wave-uniform branch)
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane_valid)
+          extra_update(CX, lin4, reinterpret_cast<const uint4*>(rin + rxofs), lout4,
+                       reinterpret_cast<const uint4*>(rout + rxofs));
+        if (out_row) {
+          if (lane_mask) {
+            int jx[P];                                    // limits relative to dx (its q is 0)
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int i = lane + 64 * v;
-      const int col = i >= nL ? tx - a.dpad + (i - nL) : tx + i;
-      pcol[v] = (i < nvals && col >= 0 && col < j.w) ? col : -1;
-    }
-    auto load_row = [&](int yy, unsigned (&pf)[MAXV]) {   // raw bytes of image row yy (0 outside the image)
-      if (yy >= 0 && yy < j.h && !(a.dbg & 8)) {
-        const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * j.lstride;
-        const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * j.rstride;
-#pragma unroll
-        for (int v = 0; v < MAXV; ++v)                    // slots below TW/64 read L, the rest R (compile time)
-          pf[v] = pcol[v] >= 0 ? (unsigned)(64 * v >= nL ? rrow : lrow)[pcol[v]] : 0u;
-      } else {
-#pragma unroll
-        for (int v = 0; v < MAXV; ++v) pf[v] = 0u;
-      }
-    };
-    const unsigned kmask = (1u << a.ksh) - 1u;
-    auto finalize = [&](int t) {                          // output row of step t: 4 pixels per lane per pass
-      const int y = ys + t - 2 * H;
-      uint4* rb = reinterpret_cast<uint4*>(rowbest + (t % NB) * TW);
-      uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride - j.ox;
-#pragma unroll
-      for (int g = 0; g < TW / 256; ++g) {
-        const int i = 4 * (lane + 64 * g);
-        const uint4 k = rb[lane + 64 * g];
-        rb[lane + 64 * g] = make_uint4(KEY_INVALID, KEY_INVALID, KEY_INVALID, KEY_INVALID);
-        unsigned char v0 = lut[k.x & kmask], v1 = lut[k.y & kmask], v2 = lut[k.z & kmask], v3 = lut[k.w & kmask];
-        const int x = tx + i;
-        if (x <= H) {                                       // x <= h: d = 0 is the only candidate (sad.go:66-69)
-          v0 = lut[0];
-          if (x + 1 <= H) v1 = lut[0];
-          if (x + 2 <= H) v2 = lut[0];
-          if (x + 3 <= H) v3 = lut[0];
-        }
-        if (x >= ox0 && x < ox1) orow[x] = v0;
-        if (x + 1 >= ox0 && x + 1 < ox1) orow[x + 1] = v1;
-        if (x + 2 >= ox0 && x + 2 < ox1) orow[x + 2] = v2;
-        if (x + 3 >= ox0 && x + 3 < ox1) orow[x + 3] = v3;
-      }
-    };
-    // Super-step s (steps t0 = s*RB .. t0+RB-1, between barrier s-1 and barrier s):
-    //   land   the rows of super-step s+1 (loaded during super-step s-1) into their ring slots,
-    //   load   the rows of super-step s+2 into the other register set,
-    //   drain  the row buffers of super-step s-1 (complete since barrier s-1) to the output.
-    // Order matters: hipcc cannot count the conditional loads / stores, so its wait before the
-    // first use of a landed register is vmcnt(0); landing first makes that wait cover only
-    // operations issued a whole super-step earlier.
-    unsigned pfa[RB][MAXV], pfb[RB][MAXV];
-#pragma unroll
-    for (int k = 0; k < RB; ++k) load_row(ys - H + RB + k, pfa[k]);       // rows of super-step 1
-    auto sstep = [&](int t0, unsigned (&land)[RB][MAXV], unsigned (&fill)[RB][MAXV]) {
-#pragma unroll
-      for (int k = 0; k < RB; ++k) {
-        const int t = t0 + RB + k;                        // step whose row is landed now
-        if (t < nsteps) {
-          unsigned* dst = ring + (t % NR) * ROWW;
-#pragma unroll
-          for (int v = 0; v < MAXV; ++v) {
-            const int i = lane + 64 * v;
-            if (i < nvals) dst[i] = land[k][v] << a.pixshift;
+            for (int p = 0; p < P; ++p) jx[p] = jlim[p] + (dc - dx);
+            reduce_row<2>(CX, jx, best, (unsigned)dx, 1);
+          } else {
+            reduce_row<1>(CX, jlim, best, (unsigned)dx, 1);
           }
         }
       }
+      if (out_row) {
+        unsigned* rb = rowbest + (t & 1) * TW + lofs;
 #pragma unroll
-      for (int k = 0; k < RB; ++k)
-        if (t0 + 2 * RB + k < nsteps) load_row(ys - H + t0 + 2 * RB + k, fill[k]);
-#pragma unroll
-      for (int k = 0; k < RB; ++k) {
-        const int t = t0 - RB + k;                        // step whose output row is drained now
-        if (t >= 2 * H && !(a.dbg & 4)) finalize(t);
+        for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]);       // ds_min_u32
       }
-      if (!(a.dbg & 16)) wg_barrier();
-    };
-    int t0 = 0;
-    for (; t0 + RB < nsteps; t0 += 2 * RB) {
-      sstep(t0, pfa, pfb);
-      sstep(t0 + RB, pfb, pfa);
+      if (t + 1 < nsteps) land_row(ring + sn * ROWW);
+      if (t - 1 >= 2 * H) finalize(t - 1);
+      wg_barrier();
+      slot_in = sn;
     }
-    if (t0 < nsteps) { sstep(t0, pfa, pfb); t0 += RB; }
-    // rows of the last super-step (complete since the last barrier)
-    for (int t = t0 - RB; t < nsteps; ++t)
-      if (t >= 2 * H && !(a.dbg & 4)) finalize(t);
+    finalize(nsteps - 1);
   }
 };
 
 
-// WB = workgroup-size bound: 1024 threads -> 128 VGPRs.  The unpacked P = 8 kernel keeps 96 column
-// sums: 512 threads (256 VGPRs, no spills) when the workgroup fits, else 768 (168 VGPRs).
+// WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
 template <int P, int ND, int H, bool PK, int WB>
 __global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK>::run(a); }
 
-struct Plan { int p, nd, nw; bool pk; };
+struct Plan { int p, nd, nw; bool pk, extra; };
 
 int env_int(const char* name, int dflt)
 {
@@ -555,30 +590,34 @@ int env_int(const char* name, int dflt)
   return e ? atoi(e) : dflt;
 }
 
-// Kernel variant for (h, D): columns per lane P, packed or not, chunk size ND and wave count NW
-// covering the D+1 candidates with the fewest idle slots (ties: fewer waves).
-//   packed   (h <= 7): P = 4 (h <= 4) with ND in {24, 12, 8}, or P = 8 with ND = 12; up to 15 waves
-//   unpacked (h == 8, or SADHIP_TUNE_PK=0): P = 4 ND {12, 8} up to 15 waves; P = 8 ND 12 up to 11 waves
+// Kernel variant for (h, D): columns per lane P, packed or not, chunk size ND, wave count NW and
+// whether the last wave carries one extra candidate (NW*ND + 1 == D + 1, the usual case: the UI's
+// D is a multiple of 16).  Cost model: a workgroup advances at the pace of its most loaded SIMD,
+// i.e. ceil(NW/4) waves of (per-candidate work * ND + per-wave overhead) per row.
+//   packed   (h <= 7): P = 4 (h <= 4), ND in {4, 8, 12, 16, 20, 24};  P = 8 (h = 5..7), ND in {4, 8, 12}
+//   unpacked (h == 8, or SADHIP_TUNE_PK=0 for comparison): P = 8, ND in {4, 8, 12}
 Plan plan_for(int h, int maxdisp)
 {
-  Plan best{0, 0, 0, false};
+  Plan best{0, 0, 0, false, false};
   if (h < 1 || h > 8 || maxdisp < 1) return best;
   const bool pk = h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0;
-  int p = h <= 4 ? 4 : 8;
-  const int fp = env_int("SADHIP_TUNE_P", 0);                   // tuning aid: force 4 or 8
-  if ((fp == 4 || fp == 8) && h <= fp) p = fp;
-  const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aid: force a chunk size
+  const int p = (h <= 4 && pk) ? 4 : 8;
+  const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aids: force a chunk size / wave count
+  const int force_nw = env_int("SADHIP_TUNE_NW", 0);
   const int cands = maxdisp + 1;
-  const int max_waves = (pk || p == 4) ? 15 : 11;               // + 1 helper wave per workgroup
-  int best_waste = 1 << 30;
-  for (int nd : {12, 24, 8}) {                               // ties: 12 (measured fastest)
+  long best_cost = 1L << 60;
+  for (int nd = 4; nd <= (p == 4 ? 24 : 12); nd += 4) {
     if (force_nd && force_nd != nd) continue;
-    if (nd == 24 && !(pk && p == 4)) continue;
-    if (nd == 8 && p == 8) continue;
-    const int nw = (cands + nd - 1) / nd;
-    if (nw > max_waves) continue;
-    const int waste = nw * nd - cands;
-    if (waste < best_waste) { best_waste = waste; best = Plan{p, nd, nw, pk}; }
+    for (int nw = 4; nw <= 16; ++nw) {
+      if (force_nw && force_nw != nw) continue;
+      const int slots = nw * nd;
+      if (slots + 1 < cands) continue;
+      const bool extra = slots + 1 == cands;
+      if (!extra && slots - nd >= cands && nw > 4) continue;   // a whole wave would be idle
+      const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
+      const long cost = (long)((nw + 3) / 4) * per_wave * 64 + nw;    // ties: fewer waves
+      if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra}; }
+    }
   }
   return best;
 }
@@ -590,10 +629,15 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   CwArgs a{};
   a.j = j;
   a.nw = pl.nw;
+  a.xw = pl.extra ? pl.nw - 1 : -1;
   a.ksh = PK ? 16 : 32 - __builtin_clz((unsigned)j.maxdisp);  // unpacked: 2^ksh > maxdisp
   a.pixshift = PK ? 0 : a.ksh;
-  a.dbg = env_int("SADHIP_TUNE_DBG", 0);
-  a.dpad = pl.nw * ND - 1;                                    // == 3 (mod 4): lane operands 16-B aligned
+  a.nomask_pen = env_int("SADHIP_TUNE_NOPEN", 0);
+  a.dpad = pl.nw * ND + 3;                                    // == 3 (mod 4): lane operands 16-B aligned
+  const int RW = K::TW + a.dpad + 1;
+  a.shl = (K::TW + pl.nw - 1) / pl.nw;
+  a.shr = (RW + pl.nw - 1) / pl.nw;
+  if (a.shl > 64 * K::MAXL || a.shr > 64 * K::MAXR) return hipErrorInvalidValue;   // cannot happen for nw >= 4
   const int r = j.w % P;
   a.tx0 = r == 0 ? 0 : r - P;
   // tiles whose output range meets [x0, x1)
@@ -604,8 +648,8 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   const int ntiles = k1 - k0 + 1;
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
-  // strip height.  About 512 workgroups are resident at once; a launch runs fastest when strips
-  // are tall (each strip repeats 2h warm-up rows): split rows only until one full round exists.
+  // strip height.  A launch runs fastest when strips are tall (each strip repeats 2h warm-up
+  // rows): split rows only until the chip is full once.
   const long want = env_int("SADHIP_TUNE_WGS", 512);          // tuning aid: target workgroup count
   long nstrips = (want + (long)ntiles * j.n - 1) / ((long)ntiles * j.n);
   const long max_strips = (rows + 15) / 16;
@@ -613,16 +657,17 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   if (nstrips < 1) nstrips = 1;
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
-  const int ROWW = 2 * K::TW + a.dpad + 1;
+  const int ROWW = K::TW + RW;
   const size_t lds = (size_t)((K::NR + 1) * ROWW + K::NB * K::TW) * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
                      + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     CwArgs aa = a;
     aa.j.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
     aa.j.left += (size_t)f0 * j.left_frame_stride;
     aa.j.right += (size_t)f0 * j.right_frame_stride;
     aa.j.out += (size_t)f0 * j.out_frame_stride;
-    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * (pl.nw + 1)), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -634,7 +679,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
 bool fast_supported(const Job& j)
 {
   if (j.w < 1 || j.h < 1) return false;
-  return plan_for(j.block / 2, j.maxdisp).nw != 0;  // BlockSize 2..17, candidates fit the wave budget
+  return plan_for(j.block / 2, j.maxdisp).nw != 0;  // BlockSize 2..17, candidates fit 16 waves
 }
 
 hipError_t launch_fast(const Job& j, hipStream_t s)
@@ -644,15 +689,16 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
   const Plan pl = plan_for(h, j.maxdisp);
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
   if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, s)
-  // packed
-  SADHIP_CASE(4, 24, 1, true); SADHIP_CASE(4, 24, 2, true); SADHIP_CASE(4, 24, 3, true); SADHIP_CASE(4, 24, 4, true);
-  SADHIP_CASE(4, 12, 1, true); SADHIP_CASE(4, 12, 2, true); SADHIP_CASE(4, 12, 3, true); SADHIP_CASE(4, 12, 4, true);
-  SADHIP_CASE(4, 8, 1, true);  SADHIP_CASE(4, 8, 2, true);  SADHIP_CASE(4, 8, 3, true);  SADHIP_CASE(4, 8, 4, true);
-  SADHIP_CASE(8, 12, 4, true); SADHIP_CASE(8, 12, 5, true); SADHIP_CASE(8, 12, 6, true); SADHIP_CASE(8, 12, 7, true);
+#define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_CASE(4, NDD, 4, true)
+#define SADHIP_P8(NDD) SADHIP_CASE(8, NDD, 5, true); SADHIP_CASE(8, NDD, 6, true); SADHIP_CASE(8, NDD, 7, true)
+  SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
+  SADHIP_P8(4); SADHIP_P8(8); SADHIP_P8(12);
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
-  if (pl.p == 8 && pl.nd == 12 && h == 8 && !pl.pk)
-    return 64 * (pl.nw + 1) <= 512 ? launch_t<8, 12, 8, false, 512>(j, pl, s) : launch_t<8, 12, 8, false, 768>(j, pl, s);
-  SADHIP_CASE(4, 12, 3, false); SADHIP_CASE(4, 12, 4, false);
+#define SADHIP_U8(NDD) \
+  if (pl.p == 8 && pl.nd == NDD && h == 8 && !pl.pk) \
+    return 64 * pl.nw <= 512 ? launch_t<8, NDD, 8, false, 512>(j, pl, s) : launch_t<8, NDD, 8, false, 1024>(j, pl, s)
+  SADHIP_U8(4); SADHIP_U8(8); SADHIP_U8(12);
+  SADHIP_CASE(8, 8, 4, false); SADHIP_CASE(8, 8, 3, false);
 #undef SADHIP_CASE
   return launch_generic(j, s);
 }

@@ -121,6 +121,36 @@ def test_random_parameter_sweep(ctx):
     assert (1, False) in kinds and (1, True) in kinds and (0, True) in kinds    # P=4, P=8 and generic all exercised
 
 
+def test_left_edge_candidate_ranges(ctx):
+    """sad.go:66-69: pixel x only has candidates d <= min(D, max(0, x-h)).  The fast kernel removes
+    the others with penalised column sums (or per-key masks for narrow frames / h = 6, 7): inputs
+    on which a missing candidate would win, or tie at the largest possible SAD, around every
+    switch-over (w vs D+2h+1, h vs 5, packed vs unpacked)."""
+    rng = np.random.default_rng(99)
+    for block in (3, 7, 9, 11, 13, 15, 16):
+        hh = block // 2
+        for D in (16, 64):
+            for w in (D + 2 * hh + 1, D + 2 * hh + 2, D + 2 * hh + 3, D + 2 * hh + 40, 300):
+                hgt = 2 * hh + 5
+                base = rng.integers(0, 256, size=(hgt, w + D), dtype=np.uint8)
+                cases = {
+                    "planted": (np.ascontiguousarray(base[:, :w]), np.ascontiguousarray(base[:, D:D + w])),   # R[x-D] = L[x]: true shift D
+                    "planted-rev": (np.ascontiguousarray(base[:, D:D + w]), np.ascontiguousarray(base[:, :w])),
+                    "extreme": (np.full((hgt, w), 255, np.uint8), np.zeros((hgt, w), np.uint8)),             # every SAD is the maximum
+                    "zero-left": (np.zeros((hgt, w), np.uint8), np.ascontiguousarray(base[:, :w])),
+                }
+                Lx = np.full((hgt, w), 255, np.uint8); Rx = np.zeros((hgt, w), np.uint8)
+                Rx[:, : w // 2] = 255                          # d = 0 is the worst candidate on the right half
+                cases["half"] = (Lx, Rx)
+                for name, (L, R) in cases.items():
+                    exp = np.minimum(_expect(L, R, block, D, raw=True), 255)
+                    got = ctx.disparity(L, R, block, D, capi.FLAG_RAW)
+                    assert np.array_equal(got, exp), (name, block, D, w)
+    L, R = sha.synth.synth_pair(41, 400, 40)
+    for reg in ((0, 0, 20, 40), (3, 5, 90, 30), (60, 0, 200, 40)):             # regions starting inside the edge zone
+        assert np.array_equal(ctx.disparity_region(L, R, 9, 64, reg), oracle.disparity_closed(L, R, 9, 64, region=reg))
+
+
 def test_tall_frame_many_strips_and_tiles(ctx):
     """Strip seams (2h warm-up rows) and tile seams (halo lanes) on a frame taller/wider than any tile."""
     L, R = sha.synth.synth_pair(77, 1100, 700)

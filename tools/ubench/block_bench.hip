@@ -6,7 +6,7 @@
 #include <cstdio>
 using namespace sadhip;
 
-template <int P, int ND, int H, int MODE, bool PK>
+template <int P, int ND, int H, int MODE, bool PK, int BARK = 1>
 __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
 {
   using K = Cw<P, ND, H, PK>;
@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
     if (MODE & 4) K::template reduce_row<2>(C, jlim, best, 0u, ND);
     if (MODE & 2 || MODE & 4) { for (int p = 0; p < P; ++p) best[p] |= 0x80000000u; }   // keep the min chain from saturating
     if (MODE & 256) { unsigned* rb = smem + 7000 + (it & 1) * 256 + 4 * (threadIdx.x & 63); for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]); }
-    if (MODE & 64) __syncthreads();
+    if ((MODE & 64) && (it % BARK) == BARK - 1) __syncthreads();
     C[0][0] += best[0] & 1;      // keep a dependency so nothing is hoisted
   }
   unsigned acc = 0;
@@ -38,17 +38,17 @@ __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
   io[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-template <int P, int ND, int H, int MODE, bool PK>
+template <int P, int ND, int H, int MODE, bool PK, int BARK = 1>
 void run(const char* name, int nw, int wgs_per_cu)
 {
   hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
   const int blocks = pr.multiProcessorCount * wgs_per_cu, iters = 2000;
   unsigned* d; hipMalloc(&d, (size_t)blocks * 1024 * 64 * 4); hipMemset(d, 1, (size_t)blocks * 1024 * 64 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k_block<P, ND, H, MODE, PK><<<blocks, 64 * nw, 32768>>>(d, 10);
+  k_block<P, ND, H, MODE, PK, BARK><<<blocks, 64 * nw, 32768>>>(d, 10);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k_block<P, ND, H, MODE, PK><<<blocks, 64 * nw, 32768>>>(d, iters);
+  k_block<P, ND, H, MODE, PK, BARK><<<blocks, 64 * nw, 32768>>>(d, iters);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double waves_per_simd = (double)nw * wgs_per_cu / 4.0;
@@ -60,14 +60,18 @@ void run(const char* name, int nw, int wgs_per_cu)
 
 int main()
 {
-  run<4, 12, 4, 2 + 32, true>("pk ND12 red nomask", 6, 4);
-  run<4, 12, 4, 4 + 32, true>("pk ND12 red lanemask", 6, 4);
   run<4, 12, 4, 3, true>("pk ND12 upd+red", 6, 4);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier", 6, 4);
-  run<4, 12, 4, 3 + 128, true>("pk ND12 upd+red +ring", 6, 4);
-  run<4, 12, 4, 3 + 256, true>("pk ND12 upd+red +ds_min", 6, 4);
-  run<4, 12, 4, 3 + 64 + 128 + 256, true>("pk ND12 upd+red +all", 6, 4);
-  run<4, 12, 4, 3 + 64 + 128 + 256, true>("pk ND12 upd+red +all", 7, 4);
-  run<4, 12, 4, 3 + 64 + 128 + 256, true>("pk ND12 upd+red +all", 6, 2);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 6, 4);
+  run<4, 12, 4, 3 + 64, true, 2>("pk ND12 upd+red +barrier/2", 6, 4);
+  run<4, 12, 4, 3 + 64, true, 4>("pk ND12 upd+red +barrier/4", 6, 4);
+  run<4, 12, 4, 3 + 64, true, 16>("pk ND12 upd+red +barrier/16", 6, 4);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 4, 6);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 8, 3);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 12, 2);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 3, 8);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 2, 12);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 1, 24);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 5, 4);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 7, 3);
   return 0;
 }
