@@ -55,7 +55,7 @@ struct CwArgs {
   int tile0;       // first tile index launched (blockIdx.x + tile0)
   int th;          // output rows per strip
   int shl, shr;    // per-wave share of a ring row: L elements (= output pixels), R elements
-  int nomask_pen;  // tuning aid: 1 = never use the penalty initialisation (per-key masks instead)
+  int nomask_pen;  // tuning aid: 1 = never use the penalty initialisation (per-key masks instead); 2 = always (timing only)
 };
 
 constexpr unsigned KEY_INVALID = 0xffffffffu;
@@ -479,7 +479,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // frames, and packed h = 6, 7, keep the per-key masks (reduce_row<2>).
     constexpr bool PEN_OK = !PK || H <= 5;
     constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
-    const bool use_pen = PEN_OK && (!PK || j.w > j.maxdisp + B1 + 1) && !a.nomask_pen;
+    const bool use_pen = (a.nomask_pen == 2) || (PEN_OK && (!PK || j.w > j.maxdisp + B1 + 1) && !a.nomask_pen);
     auto init_sum = [&](int col, int d) -> unsigned {     // start value of the column sum of (col, d)
       if constexpr (PK) {
         return (use_pen && col >= 0 && col < d && (d - 1 - col) % B1 == 0) ? PEN : 0u;

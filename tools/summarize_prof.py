@@ -17,7 +17,7 @@ if os.path.exists(st):
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['Percentage']} | {r['MinNs']} | {r['MaxNs']} |")
 tr = os.path.join(root, "trace", "trace_kernel_trace.csv")
 if os.path.exists(tr):
-    rows = [r for r in csv.DictReader(open(tr)) if "colwave" in r["Kernel_Name"] or "generic" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(tr)) if "k_colwave" in r["Kernel_Name"] or "k_disparity_generic" in r["Kernel_Name"]]
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     if d:
         thr = max(d) / 4
