@@ -55,7 +55,7 @@ struct CwArgs {
   int tile0;       // first tile index launched (blockIdx.x + tile0)
   int th;          // output rows per strip
   int shl, shr;    // per-wave share of a ring row: L elements (= output pixels), R elements
-  int nomask_pen;  // tuning aid: 1 = never use the penalty initialisation (per-key masks instead); 2 = always (timing only)
+  int nomask_pen;  // tuning aid: 2 = penalty initialisation even where it is not exact (timing only)
 };
 
 constexpr unsigned KEY_INVALID = 0xffffffffu;
@@ -136,6 +136,15 @@ __device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane 
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
 }
 
+// key where the lane's bit of a 64-bit lane mask (SGPR pair) is set, else KEY_INVALID: one
+// v_cndmask_b32 with the mask as its scalar operand -- no v_cmp, no VCC round trip.
+__device__ __forceinline__ unsigned sel_lanes(unsigned long long mask, unsigned key)
+{
+  unsigned r;
+  asm("v_cndmask_b32 %0, -1, %1, %2" : "=v"(r) : "v"(key), "s"(mask));
+  return r;
+}
+
 // Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also emits
 // s_waitcnt vmcnt(0): every wave would then sit at every row barrier until the output bytes it has
 // just stored are acknowledged (a full memory round trip per row).  Nothing depends on them;
@@ -163,6 +172,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static constexpr int NRV = P + ND;                // R values a lane loads per row (last one unused)
   static constexpr int MAXL = P / 4;                // ring-row L elements per lane (>= 4 waves share a row)
   static constexpr int MAXR = (TW + 4 * ND + 4 + 255) / 256;   // ... R elements per lane
+  static constexpr bool NEED_MASK = PK && H > 5;    // packed h = 6, 7: 2*(2h+1)^2*255 does not fit u16
+  static constexpr int NM = ND + P;                 // lane masks: one per (candidate - column), see run()
 
   // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
   // lin/lout: this lane's 4 L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
@@ -289,12 +300,15 @@ struct Cw {                                         // P columns per lane: 4 (h 
 
   // Unpacked: the window sum is the key (bias trick).  Packed: the window sums of disparities
   // dbase+2q (low half) and dbase+2q+1 (high half) become two keys (SAD << 16) | d.
-  // MASK: 0 = every candidate of the chunk is valid for every pixel; 1 = the chunk runs past
-  // MaxDisparity (wave-uniform: only the first qn candidates exist); 2 = per-pixel limits (the
-  // leftmost columns of the image, where d <= x-h cuts the range).
-  template <int MASK>
-  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const int (&jlim)[P], unsigned (&best)[P],
-                                                 unsigned dbase, int qn)
+  // MASK (packed h = 6, 7 only; every other variant removes missing candidates through the start
+  // values of the column sums, see run()): 0 = every candidate of the chunk exists for every pixel;
+  // 2 = candidate j of the wave exists for column p of lane l iff bit l of M[j - p + P-1] is set
+  // (d <= x-h near the left image edge).  plan_for() gives these variants exact plans only (no chunk
+  // runs past MaxDisparity); the extra candidate's empty high half is dropped here (qn = 1).
+  // JOFS = index of the array's first candidate within the wave (0; ND for the extra candidate).
+  template <int MASK, int JOFS>
+  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const unsigned long long (&M)[NM],
+                                                 unsigned (&best)[P], unsigned dbase, int qn)
   {
     // window sum of column p = own columns + last (h-p) columns of the left lane + first (p+h-P+1)
     // columns of the right lane.  The DPP adds are issued as two sweeps over p (all "left" pulls,
@@ -319,36 +333,36 @@ struct Cw {                                         // P columns per lane: 4 (h 
         unsigned ke = (s[p] << 16) | (dbase + 2 * q);             // v_lshl_or_b32
         unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
         if (MASK == 2) {
-          ke = (2 * q > jlim[p]) ? KEY_INVALID : ke;
-          ko = (2 * q + 1 > jlim[p]) ? KEY_INVALID : ko;
+          const int ie = JOFS + 2 * q - p + P - 1, io = ie + 1;
+          ke = sel_lanes(M[ie < NM ? ie : NM - 1], ke);
+          ko = (JOFS != 0 && 2 * q + 1 >= qn) ? KEY_INVALID : sel_lanes(M[io < NM ? io : NM - 1], ko);
         }
-        if (MASK == 1 && 2 * q + 1 >= qn) ko = KEY_INVALID;       // wave-uniform: scalar branch
         const unsigned m = ke < ko ? ke : ko;
         best[p] = m < best[p] ? m : best[p];                      // v_min3_u32
       } else {
         unsigned k = s[p];
-        if (MASK == 2) k = (q > jlim[p]) ? KEY_INVALID : k;       // d > min(D, x-h): not a candidate
+        if (MASK == 2) {
+          const int i = JOFS + q - p + P - 1;
+          k = sel_lanes(M[i < NM ? i : NM - 1], k);
+        }
         best[p] = k < best[p] ? k : best[p];
       }
     }
   }
 
-  template <int MASK, int W>
-  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const int (&jlim)[P],
+  template <int MASK, int JOFS, int W>
+  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const unsigned long long (&M)[NM],
                                                     unsigned (&best)[P], unsigned dbase, int qn)
   {
-    constexpr int CPR = PK ? 2 : 1;                            // candidates per accumulator register
     Pre cur, nxt;
     stage_a(C, 0, cur);
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-      if (MASK != 1 || CPR * q < qn) {                         // else: the rest of the chunk does not exist
-        if (q + 1 < W) stage_a(C, q + 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        stage_b<MASK>(cur, q, jlim, best, dbase, qn);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-      }
+      if (q + 1 < W) stage_a(C, q + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_b<MASK, JOFS>(cur, q, M, best, dbase, qn);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
   }
 
@@ -475,36 +489,52 @@ struct Cw {                                         // P columns per lane: 4 (h 
     //             holds exactly one column of that class, and it is < d iff c0 < d; a penalised sum
     //             is >= the worst d = 0 sum and <= 2*PEN, which fits 16 bits for h <= 5.
     // Windows clipped on the left (x <= h) only have d = 0 and are forced to lut[0] at the output;
-    // windows clipped on the right can meet missing candidates only when w <= D + 2h + 1: those
-    // frames, and packed h = 6, 7, keep the per-key masks (reduce_row<2>).
-    constexpr bool PEN_OK = !PK || H <= 5;
+    // packed windows clipped on the right can meet missing candidates only when w <= D + 2h + 2:
+    // launch_fast() sends those frames to the generic kernel.  Packed h = 6, 7 (NEED_MASK) masks
+    // keys instead: candidate j of the wave is valid for column p of lane l iff
+    // tx + P*l + p - h >= dc + j, i.e. l >= ceil((dc + h - tx + (j - p)) / P): one 64-bit lane mask
+    // per value of j - p, kept in SGPRs and applied with one v_cndmask_b32 per key.
     constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
-    const bool use_pen = (a.nomask_pen == 2) || (PEN_OK && (!PK || j.w > j.maxdisp + B1 + 1) && !a.nomask_pen);
+    const bool use_pen = !NEED_MASK || a.nomask_pen == 2;
+    unsigned long long M[NM];
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+      const int t = dc + H - tx + (k - (P - 1)) + P - 1;  // ceil(num / P) = floor((num + P-1) / P)
+      const int l0 = t > 0 ? t / P : 0;
+      M[k] = (NEED_MASK && l0 < 64) ? (~0ull << l0) : 0ull;
+    }
+    // Candidates d > D (a chunk that runs past MaxDisparity) exist for no pixel: same trick with the
+    // class c == w-1 (mod 2h+1), 0 <= c < w, which every window has exactly once -- also the windows
+    // clipped at the right image edge (they end in column w-1).  Columns >= w must start at 0: they
+    // never accumulate and their neighbours' windows sum over them.
     auto init_sum = [&](int col, int d) -> unsigned {     // start value of the column sum of (col, d)
+      const bool in = col >= 0 && col < j.w;
       if constexpr (PK) {
-        return (use_pen && col >= 0 && col < d && (d - 1 - col) % B1 == 0) ? PEN : 0u;
+        if (!use_pen || !in) return 0u;
+        if (d > j.maxdisp) return (j.w - 1 - col) % B1 == 0 ? PEN : 0u;
+        return (col < d && (d - 1 - col) % B1 == 0) ? PEN : 0u;
       } else {
         const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
-        return (biased ? (unsigned)d : 0u) + ((use_pen && col >= 0 && col < d) ? PEN : 0u);
+        return (biased ? (unsigned)d : 0u) + ((in && (col < d || d > j.maxdisp)) ? PEN : 0u);
       }
     };
     unsigned C[P][NC], CX[P][1];
-    int jlim[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int col = x0 + p;
-      jlim[p] = min(j.maxdisp, max(0, col - H)) - dc;     // candidate q valid iff q <= jlim[p]
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
         if constexpr (PK) C[p][q] = init_sum(col, dc + 2 * q) | (init_sum(col, dc + 2 * q + 1) << 16);
         else C[p][q] = init_sum(col, dc + q);
       }
-      CX[p][0] = init_sum(col, dx);
+      // the extra register's high half is candidate dx+1 > D: never updated, starts penalised
+      if constexpr (PK) CX[p][0] = init_sum(col, dx) | (init_sum(col, dx + 1) << 16);
+      else CX[p][0] = init_sum(col, dx);
     }
-    // which candidates of this wave's chunk exist?  (all wave-uniform)
+    // packed h = 6, 7: does this wave have to mask keys?  (wave-uniform)
     const int qn = min(ND, j.maxdisp - dc + 1);           // chunk runs past MaxDisparity: first qn only
-    const bool tail_mask = qn < ND;
-    const bool lane_mask = !use_pen && max(ox0, 0) - H < min(dc + ND - 1 + (xtra ? 1 : 0), j.maxdisp);
+    // some pixel of this tile has d <= x-h < chunk end (exact plans: qn == ND)
+    const bool key_mask = !use_pen && max(ox0, 0) - H < min(dc + ND - 1 + (xtra ? 1 : 0), j.maxdisp);
 
     // this lane's operands inside a ring row (u32 index): L at lofs, R value m at rofs + m
     const int lofs = P * lane;
@@ -537,15 +567,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
       const bool out_row = t >= 2 * H;
       if (lane_valid) update_columns(C, lin4, rin4, lout4, rout4);
       if (out_row) {
-        if (lane_mask) {
-#pragma unroll
-          for (int p = 0; p < P; ++p) asm volatile("" : "+v"(jlim[p]));   // keep the compares in the loop
-          reduce_row<2>(C, jlim, best, (unsigned)dc, qn);
-        } else if (tail_mask) {
-          reduce_row<1>(C, jlim, best, (unsigned)dc, qn);
-        } else {
-          reduce_row<0>(C, jlim, best, (unsigned)dc, qn);
-        }
+        if (NEED_MASK && key_mask) reduce_row<2, 0>(C, M, best, (unsigned)dc, qn);
+        else reduce_row<0, 0>(C, M, best, (unsigned)dc, qn);
       }
       if (xtra) {                                         // the odd candidate dx (wave-uniform branch)
         __builtin_amdgcn_sched_barrier(0);
@@ -553,14 +576,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
           extra_update(CX, lin4, reinterpret_cast<const uint4*>(rin + rxofs), lout4,
                        reinterpret_cast<const uint4*>(rout + rxofs));
         if (out_row) {
-          if (lane_mask) {
-            int jx[P];                                    // limits relative to dx (its q is 0)
-#pragma unroll
-            for (int p = 0; p < P; ++p) jx[p] = jlim[p] + (dc - dx);
-            reduce_row<2>(CX, jx, best, (unsigned)dx, 1);
-          } else {
-            reduce_row<1>(CX, jlim, best, (unsigned)dx, 1);
-          }
+          if constexpr (NEED_MASK) reduce_row<2, ND>(CX, M, best, (unsigned)dx, 1);   // also drops the empty high half
+          else reduce_row<0, 0>(CX, M, best, (unsigned)dx, 1);
         }
       }
       if (out_row) {
@@ -600,23 +617,31 @@ Plan plan_for(int h, int maxdisp)
 {
   Plan best{0, 0, 0, false, false};
   if (h < 1 || h > 8 || maxdisp < 1) return best;
-  const bool pk = h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0;
-  const int p = (h <= 4 && pk) ? 4 : 8;
   const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aids: force a chunk size / wave count
   const int force_nw = env_int("SADHIP_TUNE_NW", 0);
   const int cands = maxdisp + 1;
-  long best_cost = 1L << 60;
-  for (int nd = 4; nd <= (p == 4 ? 24 : 12); nd += 4) {
-    if (force_nd && force_nd != nd) continue;
-    for (int nw = 4; nw <= 16; ++nw) {
-      if (force_nw && force_nw != nw) continue;
-      const int slots = nw * nd;
-      if (slots + 1 < cands) continue;
-      const bool extra = slots + 1 == cands;
-      if (!extra && slots - nd >= cands && nw > 4) continue;   // a whole wave would be idle
-      const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
-      const long cost = (long)((nw + 3) / 4) * per_wave * 64 + nw;    // ties: fewer waves
-      if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra}; }
+  // packed first; unpacked when the window SAD does not fit 16 bits (h = 8), when forced, or when a
+  // packed h = 6, 7 kernel (key masks instead of penalties) has no exact plan for this D
+  for (int pass = (h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; pass < 2 && best.nw == 0; ++pass) {
+    const bool pk = pass == 0;
+    if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
+    const int p = (h <= 4 && pk) ? 4 : 8;
+    const bool exact_only = pk && h > 5;
+    long best_cost = 1L << 60;
+    const int nd_max = p == 4 ? 24 : ((!pk && h < 8) ? 8 : 12);  // instantiated chunk sizes
+    for (int nd = 4; nd <= nd_max; nd += 4) {
+      if (force_nd && force_nd != nd) continue;
+      for (int nw = 4; nw <= 16; ++nw) {
+        if (force_nw && force_nw != nw) continue;
+        const int slots = nw * nd;
+        if (slots + 1 < cands) continue;
+        const bool extra = slots + 1 == cands;
+        if (exact_only && !extra && slots != cands) continue;
+        if (!extra && slots - nd >= cands && nw > 4) continue;   // a whole wave would be idle
+        const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
+        const long cost = (long)((nw + 3) / 4) * per_wave * 64 + nw;    // ties: fewer waves
+        if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra}; }
+      }
     }
   }
   return best;
@@ -679,12 +704,17 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
 bool fast_supported(const Job& j)
 {
   if (j.w < 1 || j.h < 1) return false;
-  return plan_for(j.block / 2, j.maxdisp).nw != 0;  // BlockSize 2..17, candidates fit 16 waves
+  const Plan pl = plan_for(j.block / 2, j.maxdisp);  // BlockSize 2..17, candidates fit 16 waves
+  if (pl.nw == 0) return false;
+  // packed sums: a right-clipped window could meet a missing candidate without its penalty column
+  if (pl.pk && j.w <= j.maxdisp + 2 * (j.block / 2) + 2) return false;
+  return true;
 }
 
 hipError_t launch_fast(const Job& j, hipStream_t s)
 {
   if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
+  if (!fast_supported(j)) return launch_generic(j, s);
   const int h = j.block / 2;
   const Plan pl = plan_for(h, j.maxdisp);
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
@@ -694,11 +724,12 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
   SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
   SADHIP_P8(4); SADHIP_P8(8); SADHIP_P8(12);
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
-#define SADHIP_U8(NDD) \
-  if (pl.p == 8 && pl.nd == NDD && h == 8 && !pl.pk) \
-    return 64 * pl.nw <= 512 ? launch_t<8, NDD, 8, false, 512>(j, pl, s) : launch_t<8, NDD, 8, false, 1024>(j, pl, s)
-  SADHIP_U8(4); SADHIP_U8(8); SADHIP_U8(12);
-  SADHIP_CASE(8, 8, 4, false); SADHIP_CASE(8, 8, 3, false);
+#define SADHIP_U(HH, NDD) \
+  if (pl.p == 8 && pl.nd == NDD && h == HH && !pl.pk) \
+    return 64 * pl.nw <= 512 ? launch_t<8, NDD, HH, false, 512>(j, pl, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, s)
+  SADHIP_U(8, 4); SADHIP_U(8, 8); SADHIP_U(8, 12);
+  SADHIP_U(7, 4); SADHIP_U(7, 8); SADHIP_U(6, 4); SADHIP_U(6, 8);   // D without an exact packed plan
+  SADHIP_CASE(8, 8, 4, false); SADHIP_CASE(8, 8, 3, false);           // forced for comparison (SADHIP_TUNE_PK=0)
 #undef SADHIP_CASE
   return launch_generic(j, s);
 }
