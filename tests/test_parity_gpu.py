@@ -151,6 +151,30 @@ def test_left_edge_candidate_ranges(ctx):
         assert np.array_equal(ctx.disparity_region(L, R, 9, 64, reg), oracle.disparity_closed(L, R, 9, 64, region=reg))
 
 
+def test_every_plan_shape(ctx):
+    """Every way plan_for() can cover D+1 candidates: exact plans, the 16k+1-th candidate on the last
+    wave, chunks that run past MaxDisparity (candidates that exist for no pixel), packed h <= 5
+    (penalised sums), packed h = 6, 7 (lane masks; unpacked when no exact plan exists), unpacked
+    h = 8 -- on random frames and on frames whose SADs are the largest possible (u16 headroom)."""
+    rng = np.random.default_rng(7)
+    w = 420
+    for block in (3, 5, 7, 9, 11, 13, 15, 16, 17):
+        hh = block // 2
+        hgt = 2 * hh + 6
+        Lr = rng.integers(0, 256, size=(hgt, w), dtype=np.uint8)
+        Rr = rng.integers(0, 256, size=(hgt, w), dtype=np.uint8)
+        Lx = np.full((hgt, w), 255, np.uint8); Rx = np.zeros((hgt, w), np.uint8)
+        Rx[:, w // 3:] = 255; Rx[:, 2 * w // 3:] = 0
+        for D in (16, 17, 18, 19, 20, 33, 47, 64, 65, 70, 100, 128, 130, 192, 255, 256):
+            if D <= 128 or block <= 9:
+                assert capi.kernel_kind(w, hgt, block, D) == 1, (block, D)     # the column-wave kernel, not the fallback
+            for name, (L, R) in (("random", (Lr, Rr)), ("extreme", (Lx, Rx))):
+                raw = D <= 255                             # raw d is a u8: the scaled output covers D = 256
+                exp = _expect(L, R, block, D, raw=raw)
+                got = ctx.disparity(L, R, block, D, capi.FLAG_RAW if raw else 0)
+                assert np.array_equal(got, exp), (name, block, D)
+
+
 def test_tall_frame_many_strips_and_tiles(ctx):
     """Strip seams (2h warm-up rows) and tile seams (halo lanes) on a frame taller/wider than any tile."""
     L, R = sha.synth.synth_pair(77, 1100, 700)
