@@ -38,6 +38,7 @@
 //     at a lane stride of 16 bytes (ds_read_b32 at that stride was a 4-way conflict: 72 % of LDS
 //     cycles in the first version).
 #include "sadhip_kernels.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace sadhip {
@@ -625,7 +626,8 @@ Plan plan_for(int h, int maxdisp)
   for (int pass = (h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; pass < 2 && best.nw == 0; ++pass) {
     const bool pk = pass == 0;
     if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
-    const int p = (h <= 4 && pk) ? 4 : 8;
+    int p = (h <= 4 && pk) ? 4 : 8;
+    if (env_int("SADHIP_TUNE_P", 0) == 8) p = 8;                // tuning aid: 8 columns per lane for h <= 4 too
     const bool exact_only = pk && h > 5;
     long best_cost = 1L << 60;
     const int nd_max = p == 4 ? 24 : ((!pk && h < 8) ? 8 : 12);  // instantiated chunk sizes
@@ -673,10 +675,16 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   const int ntiles = k1 - k0 + 1;
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
-  // strip height.  A launch runs fastest when strips are tall (each strip repeats 2h warm-up
-  // rows): split rows only until the chip is full once.
-  const long want = env_int("SADHIP_TUNE_WGS", 512);          // tuning aid: target workgroup count
-  long nstrips = (want + (long)ntiles * j.n - 1) / ((long)ntiles * j.n);
+  // strip height.  Each strip repeats 2h warm-up rows, so strips should be tall; but the chip must
+  // be filled (small batches: split until ~512 workgroups exist), and a launch of few very long
+  // workgroups balances badly across CUs (128 pairs at 1080p: 1 strip 27.7 us/pair, 4 strips
+  // 24.2): when the batch alone fills the chip, cut strips down to ~48h rows (warm-up <= 4 %) while
+  // the grid stays <= ~4096 workgroups.
+  const long base = (long)ntiles * j.n;
+  const long want = env_int("SADHIP_TUNE_WGS", 512);          // tuning aids
+  const long rows_target = env_int("SADHIP_TUNE_ROWS", 48 * H), wg_max = env_int("SADHIP_TUNE_WGMAX", 4096);
+  long nstrips = (want + base - 1) / base;
+  if (base >= want) nstrips = std::max<long>(1, std::min<long>(rows / rows_target, wg_max / base));
   const long max_strips = (rows + 15) / 16;
   if (nstrips > max_strips) nstrips = max_strips;
   if (nstrips < 1) nstrips = 1;
@@ -723,6 +731,7 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
 #define SADHIP_P8(NDD) SADHIP_CASE(8, NDD, 5, true); SADHIP_CASE(8, NDD, 6, true); SADHIP_CASE(8, NDD, 7, true)
   SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
   SADHIP_P8(4); SADHIP_P8(8); SADHIP_P8(12);
+  SADHIP_CASE(8, 8, 4, true); SADHIP_CASE(8, 12, 4, true);     // forced for comparison (SADHIP_TUNE_P=8)
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
 #define SADHIP_U(HH, NDD) \
   if (pl.p == 8 && pl.nd == NDD && h == HH && !pl.pk) \
