@@ -128,6 +128,29 @@ __device__ __forceinline__ void pk_sad_out2(unsigned& c0, unsigned& c1, unsigned
       "v_sub_u32 %1, %1, %3"
       : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1) : "v"(l), "v"(re0), "v"(ro0), "v"(re1), "v"(ro1));
 }
+// Same for four registers (eight candidates): the temporaries of consecutive statements share
+// registers and hipcc pads that write-after-write across asm boundaries with an s_nop (a full issue
+// slot here), so fewer, larger statements.
+__device__ __forceinline__ void pk_sad_out4(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned l,
+                                            unsigned re0, unsigned ro0, unsigned re1, unsigned ro1,
+                                            unsigned re2, unsigned ro2, unsigned re3, unsigned ro3)
+{
+  unsigned t0, t1, t2, t3;
+  asm("v_sad_u8 %4, %8, %9, 0\n\t"
+      "v_sad_u8 %5, %8, %11, 0\n\t"
+      "v_sad_u8 %6, %8, %13, 0\n\t"
+      "v_sad_u8 %7, %8, %15, 0\n\t"
+      "v_sad_hi_u8 %4, %8, %10, %4\n\t"
+      "v_sad_hi_u8 %5, %8, %12, %5\n\t"
+      "v_sad_hi_u8 %6, %8, %14, %6\n\t"
+      "v_sad_hi_u8 %7, %8, %16, %7\n\t"
+      "v_sub_u32 %0, %0, %4\n\t"
+      "v_sub_u32 %1, %1, %5\n\t"
+      "v_sub_u32 %2, %2, %6\n\t"
+      "v_sub_u32 %3, %3, %7"
+      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(l), "v"(re0), "v"(ro0), "v"(re1), "v"(ro1), "v"(re2), "v"(ro2), "v"(re3), "v"(ro3));
+}
 __device__ __forceinline__ unsigned from_left(unsigned v)     // lane l <- lane l-1 (lane 0: 0)
 {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);    // wave_shr:1 bound_ctrl:0
@@ -223,11 +246,18 @@ struct Cw {                                         // P columns per lane: 4 (h 
       }
       if constexpr (PK) {
 #pragma unroll
-        for (int p = 0; p < P; ++p)
+        for (int p = 0; p < P; ++p) {
 #pragma unroll
-          for (int r = 0; r < NC; r += 2)
+          for (int r = 0; r + 4 <= NC; r += 4)
+            pk_sad_out4(C[p][r], C[p][r + 1], C[p][r + 2], C[p][r + 3], lo[p],
+                        ro[p + ND - 1 - 2 * r], ro[p + ND - 2 - 2 * r], ro[p + ND - 3 - 2 * r], ro[p + ND - 4 - 2 * r],
+                        ro[p + ND - 5 - 2 * r], ro[p + ND - 6 - 2 * r], ro[p + ND - 7 - 2 * r], ro[p + ND - 8 - 2 * r]);
+          if constexpr (NC % 4 != 0) {
+            constexpr int r = NC - 2;
             pk_sad_out2(C[p][r], C[p][r + 1], lo[p], ro[p + ND - 1 - 2 * r], ro[p + ND - 2 - 2 * r],
                         ro[p + ND - 3 - 2 * r], ro[p + ND - 4 - 2 * r]);
+          }
+        }
       } else {
 #pragma unroll
         for (int p = 0; p < P; ++p)
@@ -438,9 +468,9 @@ struct Cw {                                         // P columns per lane: 4 (h 
         const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * j.lstride;
         const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * j.rstride;
 #pragma unroll
-        for (int v = 0; v < MAXL; ++v) pfl[v] = lcol[v] >= 0 ? (unsigned)lrow[lcol[v]] : 0u;
+        for (int v = 0; v < MAXL; ++v) pfl[v] = lcol[v] >= 0 ? (unsigned)lrow[(unsigned)lcol[v]] : 0u;   // saddr + 32-bit voffset
 #pragma unroll
-        for (int v = 0; v < MAXR; ++v) pfr[v] = rcol[v] >= 0 ? (unsigned)rrow[rcol[v]] : 0u;
+        for (int v = 0; v < MAXR; ++v) pfr[v] = rcol[v] >= 0 ? (unsigned)rrow[(unsigned)rcol[v]] : 0u;
       } else {
 #pragma unroll
         for (int v = 0; v < MAXL; ++v) pfl[v] = 0u;
@@ -451,16 +481,16 @@ struct Cw {                                         // P columns per lane: 4 (h 
     auto land_row = [&](unsigned* dst) {
 #pragma unroll
       for (int v = 0; v < MAXL; ++v)
-        if (lcol[v] != -2) dst[il0 + 64 * v] = pfl[v] << a.pixshift;
+        if (lcol[v] != -2) dst[il0 + 64 * v] = PK ? pfl[v] : pfl[v] << a.pixshift;
 #pragma unroll
       for (int v = 0; v < MAXR; ++v)
-        if (rcol[v] != -2) dst[TW + ir0 + 64 * v] = pfr[v] << a.pixshift;
+        if (rcol[v] != -2) dst[TW + ir0 + 64 * v] = PK ? pfr[v] : pfr[v] << a.pixshift;
     };
     const unsigned kmask = (1u << a.ksh) - 1u;
     auto finalize = [&](int t) {                          // output row of step t, this wave's pixels
       const int y = ys + t - 2 * H;
       unsigned* rb = rowbest + (t & 1) * TW;
-      uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride - j.ox;
+      uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride;  // uniform base + 32-bit lane offset
 #pragma unroll
       for (int v = 0; v < MAXL; ++v) {
         if (lcol[v] != -2) {
@@ -470,7 +500,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
           // x <= h: d = 0 is the only candidate (sad.go:66-69)
           const unsigned d = x <= H ? 0u : min(k & kmask, (unsigned)j.maxdisp);
           const unsigned char o = lut[d];
-          if (x >= ox0 && x < ox1) orow[x] = o;
+          if (x >= ox0 && x < ox1) orow[(unsigned)(x - j.ox)] = o;
         }
       }
     };
