@@ -154,6 +154,42 @@ def SumAbsoluteDifferences(left, right, leftX, leftY, rightX, rightY, blockSize)
     return int(_context(w, h).sad_windows(left, right, blockSize, [(leftX, leftY, rightX, rightY)])[0])
 
 
+def LoadPNG(filename, refbug_rgba=False):
+    """png.go:10-41: decode, then the reference's type switch -- a gray PNG is copied
+    (gray.go:15-17), everything else goes through the Go luminance formula on alpha-premultiplied
+    channels (gray.go:43-58), computed on the device.  An opaque 8-bit RGB file decodes to
+    *image.RGBA in Go and hits convertRGBAToGray, which returns all zeros (gray.go:20-40);
+    that is reproduced only with refbug_rgba=True.  16-bit files: use the C++ mirror."""
+    from PIL import Image
+    im = Image.open(filename)
+    if im.mode in ("1", "L") and "transparency" not in im.info:
+        return np.array(im.convert("L"))
+    if im.mode == "RGB" and "transparency" not in im.info:
+        pix = np.array(im)
+        if refbug_rgba:
+            return np.zeros(pix.shape[:2], np.uint8)
+    elif im.mode in ("RGBA", "LA", "P", "L", "RGB", "1"):
+        pix = np.array(im.convert("RGBA"))        # non-premultiplied, like *image.NRGBA / the palette entries
+    else:
+        raise ValueError(f"LoadPNG {filename}: unsupported PNG mode {im.mode}")
+    h, w = pix.shape[:2]
+    return _context(w, h).gray(pix)
+
+
+def MustLoadPNG(filename):
+    return LoadPNG(filename)
+
+
+def SavePNG(filename, img):
+    """png.go:54-66: 8-bit gray, fastest compression (png.BestSpeed)."""
+    from PIL import Image
+    Image.fromarray(np.ascontiguousarray(img, np.uint8), "L").save(filename, format="PNG", compress_level=1)
+
+
+def MustSavePNG(filename, img):
+    SavePNG(filename, img)
+
+
 def run_sad_tiles(w, h, num_cpu):
     """The tile rectangles RunSad feeds (sad.go:128-153), for callers that mirror its chunking."""
     import math

@@ -1,7 +1,9 @@
 // despair.cpp -- see despair.hpp.  Host logic only; all arithmetic happens in libsadhip.so.
 #include "despair.hpp"
+#include "png_io.hpp"
 #include "../../include/sadhip.h"
 
+#include <algorithm>
 #include <atomic>
 #include <thread>
 
@@ -101,6 +103,55 @@ int SumAbsoluteDifferences(const Gray& left, const Gray& right, int leftX, int l
                               right.Pix.data(), right.Rect.Dx(), right.Rect.Dy(), right.Stride, blockSize, 1, q, &r),
         "sadhip_sad_windows_u8");
   return r;
+}
+
+// ---- png.go ------------------------------------------------------------------------------------
+Gray LoadPNG(const std::string& filename, LoadPNGOptions opt)
+{
+  PngImage im;
+  std::string err;
+  if (!read_png(filename, im, &err)) throw Error(SADHIP_ERR_ARG, "LoadPNG " + filename + ": " + err);
+  Gray g(im.w, im.h);
+  const size_t npx = (size_t)im.w * im.h;
+  switch (im.kind) {
+    case GoImage::Gray:                                         // png.go:31-32 -> gray.go:15-17
+      g.Pix = im.samples;
+      break;
+    case GoImage::RGBA:                                         // png.go:33-34 -> gray.go:20-40
+      if (opt.refbug_rgba) { std::fill(g.Pix.begin(), g.Pix.end(), 0); break; }   // 8-bit channels >> 24: always 0
+      [[fallthrough]];
+    case GoImage::NRGBA:
+    case GoImage::Paletted:                                     // png.go:35-36 -> gray.go:43-58, on the device
+      check(sadhip_gray_u8(ctx().get(opt.device, im.w, im.h), im.samples.data(), im.channels, im.w, im.h,
+                           im.w * im.channels, g.Pix.data(), g.Stride), "sadhip_gray_u8");
+      break;
+    case GoImage::Gray16:                                       // color.Gray16.RGBA() = (y, y, y): formula keeps the high byte
+      for (size_t i = 0; i < npx; ++i) {
+        const uint32_t y = (uint32_t)im.samples[2 * i] << 8 | im.samples[2 * i + 1];
+        g.Pix[i] = (uint8_t)((19595u * y + 38470u * y + 7471u * y + (1u << 15)) >> 24);
+      }
+      break;
+    case GoImage::RGBA64:
+    case GoImage::NRGBA64:                                      // 16-bit channels, NRGBA64 premultiplies r*a/0xffff
+      for (size_t i = 0; i < npx; ++i) {
+        const uint8_t* s = im.samples.data() + i * 2 * im.channels;
+        uint32_t r = (uint32_t)s[0] << 8 | s[1], gg = (uint32_t)s[2] << 8 | s[3], b = (uint32_t)s[4] << 8 | s[5];
+        if (im.channels == 4) {
+          const uint32_t a = (uint32_t)s[6] << 8 | s[7];
+          r = r * a / 0xffff; gg = gg * a / 0xffff; b = b * a / 0xffff;
+        }
+        g.Pix[i] = (uint8_t)((19595u * r + 38470u * gg + 7471u * b + (1u << 15)) >> 24);
+      }
+      break;
+  }
+  return g;
+}
+
+void SavePNG(const std::string& filename, const Gray& img)
+{
+  std::string err;
+  if (!write_png_gray8(filename, img.Pix.data(), img.Rect.Dx(), img.Rect.Dy(), img.Stride, &err))
+    throw Error(SADHIP_ERR_ARG, "SavePNG " + filename + ": " + err);
 }
 
 }  // namespace despair

@@ -11,10 +11,13 @@
 //   AssembleDisparityMap(out, dims, chunks)            despair::AssembleDisparityMap  sad.go:172-202
 //   RunSad(left, right, blockSize, maxDisparity)       despair::RunSad                sad.go:119-169
 //   SumAbsoluteDifferences(...)                        despair::SumAbsoluteDifferences sad.go:205-244
+//   LoadPNG / MustLoadPNG / SavePNG / MustSavePNG      despair::LoadPNG/...           png.go:10-76
 //
 // Deliberate differences: AssembleDisparityMap writes every chunk (the
 // reference drops the last one, sad.go:181-184); errors are exceptions carrying the C-ABI status
-// instead of panics; there is no CPU fallback.
+// instead of panics; there is no CPU fallback; LoadPNG of an opaque 8-bit RGB file returns its
+// luminance (the reference returns all zeros there, gray.go:20-40 -- LoadPNGOptions::refbug_rgba
+// reproduces that).
 #pragma once
 #include <condition_variable>
 #include <cstdint>
@@ -84,6 +87,17 @@ Pipeline SetupConcurrentSAD(int numWorkers, int device = 0);
 Gray AssembleDisparityMap(Chan<OutputChunk>& out, Rectangle dimensions, int chunks);
 // sad.go:119-169: sets the global parameters, one frame-level device call.
 Gray RunSad(const Gray& left, const Gray& right, int blockSize, int maxDisparity, int device = 0);
+// png.go:10-41: decode, then the reference's type switch -- *image.Gray is copied, everything else
+// goes through the Go luminance formula on alpha-premultiplied 16-bit channels (gray.go:43-58),
+// computed on the device for 8-bit RGB/NRGBA (sadhip_gray_u8).  Throws Error(SADHIP_ERR_ARG, ..)
+// for unreadable files (LoadPNG returns (nil, err) in Go; MustLoadPNG panics).
+struct LoadPNGOptions { bool refbug_rgba = false; int device = 0; };
+Gray LoadPNG(const std::string& filename, LoadPNGOptions opt = {});
+inline Gray MustLoadPNG(const std::string& filename) { return LoadPNG(filename); }
+// png.go:54-66: 8-bit gray PNG, fastest compression level.
+void SavePNG(const std::string& filename, const Gray& img);
+inline void MustSavePNG(const std::string& filename, const Gray& img) { SavePNG(filename, img); }
+
 // sad.go:205-244.
 int SumAbsoluteDifferences(const Gray& left, const Gray& right, int leftX, int leftY, int rightX, int rightY, int blockSize);
 

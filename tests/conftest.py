@@ -25,6 +25,7 @@ def _ensure_built():
     need = [
         (os.path.join(pkg, "lib", "libsadhip.so"), ["make", "-C", os.path.join(pkg, "csrc")]),
         (os.path.join(pkg, "lib", "run_stream"), ["make", "-C", os.path.join(pkg, "host")]),
+        (os.path.join(pkg, "lib", "png_tool"), ["make", "-C", os.path.join(pkg, "host")]),
         (os.path.join(REPO, "oracle", "libdespair_oracle.so"), ["make", "-C", os.path.join(REPO, "oracle"), "libdespair_oracle.so"]),
     ]
     for path, cmd in need:

@@ -18,7 +18,8 @@ def test_host_mirror_is_built_and_exports_the_go_api_names():
     assert os.path.exists(os.path.join(LIB, "libdespair_host.so")) and os.path.exists(EXE)
     syms = subprocess.check_output(["nm", "-DC", os.path.join(LIB, "libdespair_host.so")], text=True)
     for name in ("despair::SetupConcurrentSAD", "despair::AssembleDisparityMap", "despair::RunSad",
-                 "despair::SumAbsoluteDifferences", "despair::SetDefaultParams", "despair::DefaultParams"):
+                 "despair::SumAbsoluteDifferences", "despair::SetDefaultParams", "despair::DefaultParams",
+                 "despair::LoadPNG", "despair::SavePNG"):
         assert name in syms, name
     go = open(os.path.join(REPO, "steroscopic-hardware_amd", "host", "go", "sad_hip.go")).read()
     for name in ("func SetupConcurrentSAD(", "func RunSad(", "func AssembleDisparityMap(", "//go:build cgo && hip"):
