@@ -315,8 +315,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // Per disparity q: stage A = in-lane prefix sums ps[] and the suffix sums the right neighbour
   // needs; stage B = window sums (DPP adds pulling from both neighbour lanes) folded into best[].
   // A DPP operand must be written >= 2 instructions before the DPP op reads it, or the compiler
-  // pads with s_nop (a full issue slot each here), so the stages are software-pipelined:
-  // A(q+1) is issued between A(q) and B(q), pinned with sched_barrier.
+  // pads with s_nop (a full issue slot each here): stage A ends with the suffix subtractions the
+  // DPP adds do not read first, and the stages are pinned with sched_barrier.  (Software-pipelining
+  // A(q+1) in front of B(q) saved a few pads but cost 13-18 VGPRs in the P = 8 variants and was
+  // no faster anywhere.)
   struct Pre { unsigned ps[P + 1]; unsigned suf[P + 1]; };   // suf[k] = sum of the lane's last k columns
 
   template <int W>
@@ -385,15 +387,13 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const unsigned long long (&M)[NM],
                                                     unsigned (&best)[P], unsigned dbase, int qn)
   {
-    Pre cur, nxt;
-    stage_a(C, 0, cur);
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-      if (q + 1 < W) stage_a(C, q + 1, nxt);
+      Pre cur;
+      stage_a(C, q, cur);
       __builtin_amdgcn_sched_barrier(0);
       stage_b<MASK, JOFS>(cur, q, M, best, dbase, qn);
       __builtin_amdgcn_sched_barrier(0);
-      cur = nxt;
     }
   }
 
@@ -765,7 +765,7 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
 #define SADHIP_U(HH, NDD) \
   if (pl.p == 8 && pl.nd == NDD && h == HH && !pl.pk) \
-    return 64 * pl.nw <= 512 ? launch_t<8, NDD, HH, false, 512>(j, pl, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, s)
+    return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, s)
   SADHIP_U(8, 4); SADHIP_U(8, 8); SADHIP_U(8, 12);
   SADHIP_U(7, 4); SADHIP_U(7, 8); SADHIP_U(6, 4); SADHIP_U(6, 8);   // D without an exact packed plan
   SADHIP_CASE(8, 8, 4, false); SADHIP_CASE(8, 8, 3, false);           // forced for comparison (SADHIP_TUNE_PK=0)
