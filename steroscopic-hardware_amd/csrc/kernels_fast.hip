@@ -40,6 +40,7 @@
 #include "sadhip_kernels.h"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace sadhip {
 
@@ -57,6 +58,13 @@ struct CwArgs {
   int th;          // output rows per strip
   int shl, shr;    // per-wave share of a ring row: L elements (= output pixels), R elements
   int nomask_pen;  // tuning aid: 2 = penalty initialisation even where it is not exact (timing only)
+  // Disparity ranges wider than one workgroup can hold run as several passes (launches) over
+  // candidates [dbase, dbase + nw*ND (+1)): a pass merges its per-pixel keys with the keys of the
+  // passes before it (kin) and hands them on (kout); the last pass writes the u8 output.
+  int dbase;
+  const unsigned* kin;     // keys so far, or nullptr (first pass)
+  unsigned* kout;          // where to leave the keys, or nullptr (last pass: write the output)
+  int kw;                  // u32 per key row (= x1 - x0); key of (f, y, x) at (f*rows + y-y0)*kw + x-x0
 };
 
 constexpr unsigned KEY_INVALID = 0xffffffffu;
@@ -405,7 +413,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dc = wv * ND;                               // first disparity of this wave
+    const int dcl = wv * ND;                              // first disparity of this wave within the pass
+    const int dc = a.dbase + dcl;                         // ... and absolute
     const int RW = TW + a.dpad + 1;                       // R values per ring row (multiple of 4)
     const int ROWW = TW + RW;                             // u32 per ring row: L[TW] then R[RW]
     unsigned* ring = smem;                                // (NR + 1) rows; row NR stays zero
@@ -427,7 +436,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
     if (ys >= ye || ox0 >= ox1) return;
 
     // ---- one-time setup: zero row, row-best buffers, output LUT, first ring row ----------------
-    // Ring row of image row yy: L columns [tx, tx+TW) then R columns [tx-dpad, tx+TW), one u32 per
+    // Ring row of image row yy: L columns [tx, tx+TW) then R columns [tx-dbase-dpad, tx-dbase+TW), one u32 per
     // pixel (shifted by ksh in the unpacked variant), zero outside the image.
     for (int i = tid; i < ROWW; i += nt) ring[NR * ROWW + i] = 0;
     for (int i = tid; i < NB * TW; i += nt) rowbest[i] = KEY_INVALID;
@@ -437,7 +446,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
       const int yy = ys - H;                              // step 0's entering row -> slot 0
       for (int i = tid; i < ROWW; i += nt) {
         const bool isR = i >= TW;
-        const int col = isR ? tx - a.dpad + (i - TW) : tx + i;
+        const int col = isR ? tx - a.dbase - a.dpad + (i - TW) : tx + i;
         unsigned v = 0u;
         if (yy >= 0 && yy < j.h && col >= 0 && col < j.w)
           v = (unsigned)(isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride)[col];
@@ -459,7 +468,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
     }
 #pragma unroll
     for (int v = 0; v < MAXR; ++v) {
-      const int i = ir0 + 64 * v, col = tx - a.dpad + i;
+      const int i = ir0 + 64 * v, col = tx - a.dbase - a.dpad + i;
       rcol[v] = (lane + 64 * v < a.shr && i < RW) ? ((col >= 0 && col < j.w) ? col : -1) : -2;
     }
     unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
@@ -491,16 +500,23 @@ struct Cw {                                         // P columns per lane: 4 (h 
       const int y = ys + t - 2 * H;
       unsigned* rb = rowbest + (t & 1) * TW;
       uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride;  // uniform base + 32-bit lane offset
+      const size_t krow = ((size_t)f * (j.y1 - j.y0) + (y - j.y0)) * a.kw;
 #pragma unroll
       for (int v = 0; v < MAXL; ++v) {
         if (lcol[v] != -2) {
           const int i = il0 + 64 * v, x = tx + i;
-          const unsigned k = rb[i];
+          unsigned k = rb[i];
           rb[i] = KEY_INVALID;
-          // x <= h: d = 0 is the only candidate (sad.go:66-69)
-          const unsigned d = x <= H ? 0u : min(k & kmask, (unsigned)j.maxdisp);
-          const unsigned char o = lut[d];
-          if (x >= ox0 && x < ox1) orow[(unsigned)(x - j.ox)] = o;
+          if (x >= ox0 && x < ox1) {
+            if (a.kin) k = min(k, a.kin[krow + (unsigned)(x - j.x0)]);
+            if (a.kout) {
+              a.kout[krow + (unsigned)(x - j.x0)] = k;
+            } else {
+              // x <= h: d = 0 is the only candidate (sad.go:66-69)
+              const unsigned d = x <= H ? 0u : min(k & kmask, (unsigned)j.maxdisp);
+              orow[(unsigned)(x - j.ox)] = lut[d];
+            }
+          }
         }
       }
     };
@@ -509,7 +525,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int x0 = tx + P * lane;                         // first column of this lane
     const bool lane_valid = x0 < j.w;                     // (w - tx) % P == 0: all-or-nothing
     const bool xtra = wv == a.xw;                         // this wave also owns candidate dx = nw*ND
-    const int dx = a.nw * ND;
+    const int dx = a.dbase + a.nw * ND;
     // Candidates d > x-h do not exist near the left image edge (sad.go:66-69).  Instead of masking
     // their keys in every row (which made the leftmost tile's workgroups the critical path of the
     // whole launch), their column sums start with a penalty that outlives the sliding updates:
@@ -569,8 +585,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
 
     // this lane's operands inside a ring row (u32 index): L at lofs, R value m at rofs + m
     const int lofs = P * lane;
-    const int rofs = TW + (a.dpad - dc - (ND - 1)) + P * lane;        // multiple of 4 by construction
-    const int rxofs = TW + (a.dpad - dx - 3) + P * lane;              // extra candidate: R value of column p at +3+p
+    const int rofs = TW + (a.dpad - dcl - (ND - 1)) + P * lane;       // multiple of 4 by construction
+    const int rxofs = TW + (a.dpad - a.nw * ND - 3) + P * lane;       // extra candidate: R value of column p at +3+p
 
     // ---- main loop: step t brings in image row ys-H+t (ring slot t % NR) ------------------------
     //   load    this wave's share of row t+1 (global -> registers; lands after the arithmetic)
@@ -631,6 +647,8 @@ template <int P, int ND, int H, bool PK, int WB>
 __global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK>::run(a); }
 
 struct Plan { int p, nd, nw; bool pk, extra; };
+struct Pass { Plan pl; int dbase; };              // candidates [dbase, dbase + nw*nd (+1)) of the job
+struct PassIo { int dbase; const unsigned* kin; unsigned* kout; int kw; };
 
 int env_int(const char* name, int dflt)
 {
@@ -638,49 +656,74 @@ int env_int(const char* name, int dflt)
   return e ? atoi(e) : dflt;
 }
 
-// Kernel variant for (h, D): columns per lane P, packed or not, chunk size ND, wave count NW and
-// whether the last wave carries one extra candidate (NW*ND + 1 == D + 1, the usual case: the UI's
-// D is a multiple of 16).  Cost model: a workgroup advances at the pace of its most loaded SIMD,
-// i.e. ceil(NW/4) waves of (per-candidate work * ND + per-wave overhead) per row.
+// Kernel variant for `count` consecutive candidates: columns per lane P, packed or not, chunk size
+// ND, wave count NW and whether the last wave carries one extra candidate (NW*ND + 1 == count, the
+// usual case: the UI's D is a multiple of 16).  Cost model: a workgroup advances at the pace of
+// its most loaded SIMD, i.e. ceil(NW/4) waves of (per-candidate work * ND + per-wave overhead) per
+// row.  exact: no chunk may run past the last candidate (packed h = 6, 7 masks keys with lane masks
+// that cannot express it).
 //   packed   (h <= 7): P = 4 (h <= 4), ND in {4, 8, 12, 16, 20, 24};  P = 8 (h = 5..7), ND in {4, 8, 12}
-//   unpacked (h == 8, or SADHIP_TUNE_PK=0 for comparison): P = 8, ND in {4, 8, 12}
-Plan plan_for(int h, int maxdisp)
+//   unpacked (h = 8; h = 6, 7 without an exact packed plan; SADHIP_TUNE_PK=0): P = 8, ND in {4, 8, 12}
+Plan plan_count(int h, bool pk, int count, bool exact)
 {
   Plan best{0, 0, 0, false, false};
-  if (h < 1 || h > 8 || maxdisp < 1) return best;
   const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aids: force a chunk size / wave count
   const int force_nw = env_int("SADHIP_TUNE_NW", 0);
-  const int cands = maxdisp + 1;
-  // packed first; unpacked when the window SAD does not fit 16 bits (h = 8), when forced, or when a
-  // packed h = 6, 7 kernel (key masks instead of penalties) has no exact plan for this D
-  for (int pass = (h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; pass < 2 && best.nw == 0; ++pass) {
-    const bool pk = pass == 0;
-    if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
-    int p = (h <= 4 && pk) ? 4 : 8;
-    if (env_int("SADHIP_TUNE_P", 0) == 8) p = 8;                // tuning aid: 8 columns per lane for h <= 4 too
-    const bool exact_only = pk && h > 5;
-    long best_cost = 1L << 60;
-    const int nd_max = p == 4 ? 24 : ((!pk && h < 8) ? 8 : 12);  // instantiated chunk sizes
-    for (int nd = 4; nd <= nd_max; nd += 4) {
-      if (force_nd && force_nd != nd) continue;
-      for (int nw = 4; nw <= 16; ++nw) {
-        if (force_nw && force_nw != nw) continue;
-        const int slots = nw * nd;
-        if (slots + 1 < cands) continue;
-        const bool extra = slots + 1 == cands;
-        if (exact_only && !extra && slots != cands) continue;
-        if (!extra && slots - nd >= cands && nw > 4) continue;   // a whole wave would be idle
-        const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
-        const long cost = (long)((nw + 3) / 4) * per_wave * 64 + nw;    // ties: fewer waves
-        if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra}; }
-      }
+  int p = (h <= 4 && pk) ? 4 : 8;
+  if (env_int("SADHIP_TUNE_P", 0) == 8) p = 8;                  // tuning aid: 8 columns per lane for h <= 4 too
+  long best_cost = 1L << 60;
+  const int nd_max = p == 4 ? 24 : ((!pk && h < 8) ? 8 : 12);    // instantiated chunk sizes
+  for (int nd = 4; nd <= nd_max; nd += 4) {
+    if (force_nd && force_nd != nd) continue;
+    for (int nw = 4; nw <= 16; ++nw) {
+      if (force_nw && force_nw != nw) continue;
+      if (!pk && nd == 12 && nw > 8) continue;                  // unpacked ND 12 needs the 512-thread register budget
+      const int slots = nw * nd;
+      if (slots + 1 < count) continue;
+      const bool extra = slots + 1 == count;
+      if (exact && !extra && slots != count) continue;
+      if (!extra && slots - nd >= count && nw > 4) continue;    // a whole wave would be idle
+      const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
+      const long cost = (long)((nw + 3) / 4) * per_wave * 64 + nw;    // ties: fewer waves
+      if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra}; }
     }
   }
   return best;
 }
 
+// The whole disparity range [0, D] as one pass, or -- when D+1 candidates do not fit the 16 waves
+// of a workgroup -- as several passes of 16 full waves plus a last pass for the rest (see CwArgs).
+// Packed first; unpacked when the window SAD does not fit 16 bits (h = 8), when forced, or when a
+// packed h = 6, 7 kernel has no exact plan.  Empty result: the generic kernel runs the job.
+std::vector<Pass> plan_job(int h, int maxdisp)
+{
+  std::vector<Pass> passes;
+  if (h < 1 || h > 8 || maxdisp < 1) return passes;
+  for (int variant = (h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; variant < 2; ++variant) {
+    const bool pk = variant == 0;
+    if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
+    if (!pk && maxdisp > 1023) break;                           // unpacked keys (SAD << bitlen(D)) must stay below the 2^27 penalty
+    const bool exact = pk && h > 5;
+    const int chunk = 16 * ((h <= 4 && pk) ? 16 : 8);           // 16 waves of ND 16 (P 4) / ND 8 (P 8)
+    passes.clear();
+    int base = 0, rem = maxdisp + 1;
+    while (rem > 0) {
+      Plan pl = plan_count(h, pk, rem, exact);
+      if (pl.nw) { passes.push_back(Pass{pl, base}); rem = 0; break; }
+      if (rem <= chunk) break;                                  // no plan for the rest
+      pl = plan_count(h, pk, chunk, true);
+      if (!pl.nw) break;
+      passes.push_back(Pass{pl, base});
+      base += chunk; rem -= chunk;
+    }
+    if (rem == 0) return passes;
+  }
+  passes.clear();
+  return passes;
+}
+
 template <int P, int ND, int H, bool PK, int WB = 1024>
-hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
+hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s)
 {
   using K = Cw<P, ND, H, PK>;
   CwArgs a{};
@@ -690,6 +733,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
   a.ksh = PK ? 16 : 32 - __builtin_clz((unsigned)j.maxdisp);  // unpacked: 2^ksh > maxdisp
   a.pixshift = PK ? 0 : a.ksh;
   a.nomask_pen = env_int("SADHIP_TUNE_NOPEN", 0);
+  a.dbase = io.dbase; a.kin = io.kin; a.kout = io.kout; a.kw = io.kw;
   a.dpad = pl.nw * ND + 3;                                    // == 3 (mod 4): lane operands 16-B aligned
   const int RW = K::TW + a.dpad + 1;
   a.shl = (K::TW + pl.nw - 1) / pl.nw;
@@ -742,21 +786,18 @@ hipError_t launch_t(const Job& j, const Plan& pl, hipStream_t s)
 bool fast_supported(const Job& j)
 {
   if (j.w < 1 || j.h < 1) return false;
-  const Plan pl = plan_for(j.block / 2, j.maxdisp);  // BlockSize 2..17, candidates fit 16 waves
-  if (pl.nw == 0) return false;
+  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp);   // BlockSize 2..17
+  if (passes.empty()) return false;
   // packed sums: a right-clipped window could meet a missing candidate without its penalty column
-  if (pl.pk && j.w <= j.maxdisp + 2 * (j.block / 2) + 2) return false;
+  if (passes[0].pl.pk && j.w <= j.maxdisp + 2 * (j.block / 2) + 2) return false;
   return true;
 }
 
-hipError_t launch_fast(const Job& j, hipStream_t s)
+static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s)
 {
-  if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
-  if (!fast_supported(j)) return launch_generic(j, s);
   const int h = j.block / 2;
-  const Plan pl = plan_for(h, j.maxdisp);
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
-  if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, s)
+  if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s)
 #define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_CASE(4, NDD, 4, true)
 #define SADHIP_P8(NDD) SADHIP_CASE(8, NDD, 5, true); SADHIP_CASE(8, NDD, 6, true); SADHIP_CASE(8, NDD, 7, true)
   SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
@@ -765,12 +806,42 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
 #define SADHIP_U(HH, NDD) \
   if (pl.p == 8 && pl.nd == NDD && h == HH && !pl.pk) \
-    return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, s)
+    return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, io, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, io, s)
   SADHIP_U(8, 4); SADHIP_U(8, 8); SADHIP_U(8, 12);
   SADHIP_U(7, 4); SADHIP_U(7, 8); SADHIP_U(6, 4); SADHIP_U(6, 8);   // D without an exact packed plan
   SADHIP_CASE(8, 8, 4, false); SADHIP_CASE(8, 8, 3, false);           // forced for comparison (SADHIP_TUNE_PK=0)
 #undef SADHIP_CASE
-  return launch_generic(j, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_fast(const Job& j, hipStream_t s)
+{
+  if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
+  if (!fast_supported(j)) return launch_generic(j, s);
+  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp);
+  if (passes.size() == 1) {
+    const hipError_t e = launch_pass(j, passes[0].pl, PassIo{0, nullptr, nullptr, 0}, s);
+    return e == hipErrorInvalidValue ? launch_generic(j, s) : e;
+  }
+  // several passes: a u32 key per output pixel travels from pass to pass in a stream-ordered
+  // scratch buffer (<= 256 MB: frames are processed in chunks)
+  const int kw = j.x1 - j.x0, rows = j.y1 - j.y0;
+  const size_t per_frame = (size_t)kw * rows * sizeof(unsigned);
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)j.n, ((size_t)256 << 20) / per_frame));
+  unsigned* keys = nullptr;
+  hipError_t e = hipMallocAsync((void**)&keys, per_frame * chunk, s);
+  if (e != hipSuccess) return e;
+  for (int f0 = 0; f0 < j.n && e == hipSuccess; f0 += chunk) {
+    Job jj = j;
+    jj.n = std::min(chunk, j.n - f0);
+    jj.left += (size_t)f0 * j.left_frame_stride;
+    jj.right += (size_t)f0 * j.right_frame_stride;
+    jj.out += (size_t)f0 * j.out_frame_stride;
+    for (size_t k = 0; k < passes.size() && e == hipSuccess; ++k)
+      e = launch_pass(jj, passes[k].pl, PassIo{passes[k].dbase, k ? keys : nullptr, k + 1 < passes.size() ? keys : nullptr, kw}, s);
+  }
+  const hipError_t ef = hipFreeAsync(keys, s);
+  return e != hipSuccess ? e : ef;
 }
 
 }  // namespace sadhip

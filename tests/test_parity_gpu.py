@@ -175,6 +175,34 @@ def test_every_plan_shape(ctx):
                 assert np.array_equal(got, exp), (name, block, D)
 
 
+def test_multi_pass_disparity_ranges(ctx):
+    """D+1 candidates beyond the 16 waves of a workgroup run as several launches that hand a u32 key
+    per pixel from pass to pass (kernels_fast.hip, plan_job): every UI value of MaxDisparity
+    (cmd/handlers/params.go:45-52: up to 256) for every BlockSize the column-wave kernel covers,
+    and larger ranges, incl. frames whose SADs are the largest possible."""
+    rng = np.random.default_rng(11)
+    for block, Ds in ((9, (400, 500)), (11, (208, 224, 240, 256, 300)), (13, (208, 256)), (15, (208, 224, 240, 256)),
+                      (16, (208, 256, 300)), (17, (256,))):
+        hh = block // 2
+        hgt = 2 * hh + 5
+        for D in Ds:
+            w = D + 2 * hh + 150
+            assert capi.kernel_kind(w, hgt, block, D) == 1, (block, D)
+            Lr = rng.integers(0, 256, size=(hgt, w), dtype=np.uint8)
+            Rr = np.roll(Lr, -(D - 3), axis=1)                 # true shift D-3: found only in the last pass
+            Rr[:, -(D - 3):] = rng.integers(0, 256, size=(hgt, D - 3), dtype=np.uint8)
+            Lx = np.full((hgt, w), 255, np.uint8); Rx = np.zeros((hgt, w), np.uint8); Rx[:, w // 2:] = 255
+            for name, (L, R) in (("shifted", (Lr, Rr)), ("extreme", (Lx, Rx))):
+                got = ctx.disparity(L, R, block, D)
+                assert np.array_equal(got, _expect(L, R, block, D)), (name, block, D)
+    L, R = sha.synth.synth_pair(91, 900, 60)                    # a batch (frames chunked against the key scratch) and a region
+    got = ctx.disparity_batch([L, R, L], [R, L, L], 11, 256)
+    for g, (a, b) in zip(got, ((L, R), (R, L), (L, L))):
+        assert np.array_equal(g, _expect(a, b, 11, 256))
+    reg = (300, 7, 777, 51)
+    assert np.array_equal(ctx.disparity_region(L, R, 15, 240, reg), oracle.disparity_closed(L, R, 15, 240, region=reg))
+
+
 def test_tall_frame_many_strips_and_tiles(ctx):
     """Strip seams (2h warm-up rows) and tile seams (halo lanes) on a frame taller/wider than any tile."""
     L, R = sha.synth.synth_pair(77, 1100, 700)
