@@ -39,6 +39,7 @@
 //     cycles in the first version).
 #include "sadhip_kernels.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -188,12 +189,13 @@ __device__ __forceinline__ void wg_barrier()
 }
 
 template <int P, int ND, int H, bool PK>
-struct Cw {                                         // P columns per lane: 4 (h <= 4) or 8 (h <= 8)
+struct Cw {                                         // P columns per lane: 4 (h <= 4) or 8 (h <= 15)
   // PK: column sums of disparity pairs packed as u16 halves (window SAD < 65536, i.e. h <= 7)
   static_assert(!PK || (H <= 7 && ND % 4 == 0), "packed sums need (2h+1)^2 * 255 < 65536");
   static constexpr int NC = PK ? ND / 2 : ND;       // accumulator registers per column
   static_assert(P == 4 || P == 8, "operand reads are whole ds_read_b128");
-  static_assert(H >= 1 && H <= P, "halo must fit in the neighbour lane");
+  static_assert(H >= 1 && H <= 2 * P - 1, "halo must fit in the two neighbour lanes on each side");
+  static_assert(H <= P || !PK, "two-lane halos exist for the unpacked variant only");
   static_assert(ND % 4 == 0, "ND must keep every lane's R operands 16-byte aligned");
   static constexpr int TW = 64 * P;                 // columns per tile
   static constexpr int OL = P * ((H + P - 1) / P);  // first output column inside the tile
@@ -356,18 +358,44 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // then all "right" pulls): a DPP instruction that reads a VGPR written by the instruction just
     // before it costs wait states, so the two adds of one column are kept P instructions apart.
     unsigned s[P];
+    if constexpr (H <= P) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int a = p - H, b = p + H;
-      const int lo = a > 0 ? a : 0, hi = b < P - 1 ? b : P - 1;
-      s[p] = lo == 0 ? r.ps[hi + 1] : r.ps[hi + 1] - r.ps[lo];
-      if (a < 0) s[p] += from_left(r.suf[-a]);
+      for (int p = 0; p < P; ++p) {
+        const int a = p - H, b = p + H;
+        const int lo = a > 0 ? a : 0, hi = b < P - 1 ? b : P - 1;
+        s[p] = lo == 0 ? r.ps[hi + 1] : r.ps[hi + 1] - r.ps[lo];
+        if (a < 0) s[p] += from_left(r.suf[-a]);
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));      // v_add_u32_dpp twice, not v_mov_dpp x2 + v_add3
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (p + H > P - 1) s[p] += from_right(r.ps[p + H - P + 1]);
+    } else {
+      // P < h < 2P (BlockSize 19..31): the window covers the whole lane, up to the whole neighbour
+      // lane on each side, and H-p-P (left) / p+H-2P+1 (right) columns of the lane after that:
+      // the neighbours' totals once, the second hop as v_mov_dpp of the partial sum followed by a
+      // DPP add one lane further.
+      constexpr int N2 = H - P;                              // most columns needed from a lane two away
+      unsigned t2l[N2 + 1], t2r[N2 + 1];
+      const unsigned tl = from_left(r.ps[P]), tr = from_right(r.ps[P]);
+#pragma unroll
+      for (int k = 1; k <= N2; ++k) { t2l[k] = from_left(r.suf[k]); t2r[k] = from_right(r.ps[k]); }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int nl = H - p;                                // columns left of the lane (>= H-P+1 > 0)
+        if (nl >= P) { s[p] = r.ps[P] + tl; if (nl > P) s[p] += from_left(t2l[nl - P]); }
+        else s[p] = r.ps[P] + from_left(r.suf[nl]);
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int nr = p + H - P + 1;                        // columns right of the lane (> 0)
+        if (nr >= P) { s[p] += tr; if (nr > P) s[p] += from_right(t2r[nr - P]); }
+        else s[p] += from_right(r.ps[nr]);
+      }
     }
-#pragma unroll
-    for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));        // v_add_u32_dpp twice, not v_mov_dpp x2 + v_add3
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-      if (p + H > P - 1) s[p] += from_right(r.ps[p + H - P + 1]);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       if constexpr (PK) {
@@ -664,7 +692,7 @@ int env_int(const char* name, int dflt)
 // that cannot express it).
 //   packed   (h <= 7): P = 4 (h <= 4), ND in {4, 8, 12, 16, 20, 24};  P = 8 (h = 5..7), ND in {4, 8, 12}
 //   unpacked (h = 8; h = 6, 7 without an exact packed plan; SADHIP_TUNE_PK=0): P = 8, ND in {4, 8, 12}
-Plan plan_count(int h, bool pk, int count, bool exact)
+Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
 {
   Plan best{0, 0, 0, false, false};
   const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aids: force a chunk size / wave count
@@ -672,12 +700,15 @@ Plan plan_count(int h, bool pk, int count, bool exact)
   int p = (h <= 4 && pk) ? 4 : 8;
   if (env_int("SADHIP_TUNE_P", 0) == 8) p = 8;                  // tuning aid: 8 columns per lane for h <= 4 too
   long best_cost = 1L << 60;
-  const int nd_max = p == 4 ? 24 : ((!pk && h < 8) ? 8 : 12);    // instantiated chunk sizes
+  const int nd_max = p == 4 ? 24 : ((!pk && h != 8) ? 8 : 12);   // instantiated chunk sizes (unpacked ND 12: h = 8 only)
   for (int nd = 4; nd <= nd_max; nd += 4) {
     if (force_nd && force_nd != nd) continue;
     for (int nw = 4; nw <= 16; ++nw) {
       if (force_nw && force_nw != nw) continue;
       if (!pk && nd == 12 && nw > 8) continue;                  // unpacked ND 12 needs the 512-thread register budget
+      if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
+      // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4] u32, two row buffers, the output LUT
+      if ((size_t)((2 * h + 4) * (2 * 64 * p + nw * nd + 4) + 2 * 64 * p) * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
       const int slots = nw * nd;
       if (slots + 1 < count) continue;
       const bool extra = slots + 1 == count;
@@ -698,20 +729,23 @@ Plan plan_count(int h, bool pk, int count, bool exact)
 std::vector<Pass> plan_job(int h, int maxdisp)
 {
   std::vector<Pass> passes;
-  if (h < 1 || h > 8 || maxdisp < 1) return passes;
+  if (h < 1 || h > 15 || maxdisp < 1) return passes;
   for (int variant = (h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; variant < 2; ++variant) {
     const bool pk = variant == 0;
     if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
-    if (!pk && maxdisp > 1023) break;                           // unpacked keys (SAD << bitlen(D)) must stay below the 2^27 penalty
+    // unpacked keys ((2h+1)^2*255 << bitlen(D)) must stay below the 2^27 penalty
+    const int b1 = 2 * h + 1, ksh = 32 - __builtin_clz((unsigned)maxdisp);
+    if (!pk && ((long long)b1 * b1 * 255 << ksh) >= (1LL << 27)) break;
     const bool exact = pk && h > 5;
-    const int chunk = 16 * ((h <= 4 && pk) ? 16 : 8);           // 16 waves of ND 16 (P 4) / ND 8 (P 8)
+    // full passes: 16 waves of ND 16 (P 4) / ND 8 (P 8); two-lane halos: 8 waves of ND 8
+    const int chunk = (h <= 4 && pk) ? 256 : (h <= 8 ? 128 : 64);
     passes.clear();
     int base = 0, rem = maxdisp + 1;
     while (rem > 0) {
-      Plan pl = plan_count(h, pk, rem, exact);
+      Plan pl = plan_count(h, pk, rem, exact, maxdisp);
       if (pl.nw) { passes.push_back(Pass{pl, base}); rem = 0; break; }
       if (rem <= chunk) break;                                  // no plan for the rest
-      pl = plan_count(h, pk, chunk, true);
+      pl = plan_count(h, pk, chunk, true, maxdisp);
       if (!pl.nw) break;
       passes.push_back(Pass{pl, base});
       base += chunk; rem -= chunk;
@@ -786,7 +820,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
 bool fast_supported(const Job& j)
 {
   if (j.w < 1 || j.h < 1) return false;
-  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp);   // BlockSize 2..17
+  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp);   // BlockSize 2..31
   if (passes.empty()) return false;
   // packed sums: a right-clipped window could meet a missing candidate without its penalty column
   if (passes[0].pl.pk && j.w <= j.maxdisp + 2 * (j.block / 2) + 2) return false;
@@ -809,6 +843,8 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
     return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, io, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, io, s)
   SADHIP_U(8, 4); SADHIP_U(8, 8); SADHIP_U(8, 12);
   SADHIP_U(7, 4); SADHIP_U(7, 8); SADHIP_U(6, 4); SADHIP_U(6, 8);   // D without an exact packed plan
+#define SADHIP_UH(HH) SADHIP_U(HH, 4); if (pl.p == 8 && pl.nd == 8 && h == HH && !pl.pk) return launch_t<8, 8, HH, false, 512>(j, pl, io, s)
+  SADHIP_UH(9); SADHIP_UH(10); SADHIP_UH(11); SADHIP_UH(12); SADHIP_UH(13); SADHIP_UH(14); SADHIP_UH(15);   // BlockSize 18..31: two-lane halos
   SADHIP_CASE(8, 8, 4, false); SADHIP_CASE(8, 8, 3, false);           // forced for comparison (SADHIP_TUNE_PK=0)
 #undef SADHIP_CASE
   return hipErrorInvalidValue;
@@ -837,8 +873,12 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
     jj.left += (size_t)f0 * j.left_frame_stride;
     jj.right += (size_t)f0 * j.right_frame_stride;
     jj.out += (size_t)f0 * j.out_frame_stride;
-    for (size_t k = 0; k < passes.size() && e == hipSuccess; ++k)
+    for (size_t k = 0; k < passes.size() && e == hipSuccess; ++k) {
       e = launch_pass(jj, passes[k].pl, PassIo{passes[k].dbase, k ? keys : nullptr, k + 1 < passes.size() ? keys : nullptr, kw}, s);
+      if (env_int("SADHIP_TUNE_VERBOSE", 0))
+        fprintf(stderr, "sadhip: pass %zu/%zu dbase %d p %d nd %d nw %d pk %d extra %d -> %s\n", k, passes.size(), passes[k].dbase,
+                passes[k].pl.p, passes[k].pl.nd, passes[k].pl.nw, (int)passes[k].pl.pk, (int)passes[k].pl.extra, hipGetErrorString(e));
+    }
   }
   const hipError_t ef = hipFreeAsync(keys, s);
   return e != hipSuccess ? e : ef;

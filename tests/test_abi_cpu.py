@@ -91,3 +91,16 @@ def test_despair_param_plumbing_and_tiles():
     for x0, y0, x1, y1 in rects:
         cover[y0:y1, x0:x1] += 1
     assert (cover == 1).all()
+
+
+def test_whole_ui_parameter_grid_plans_on_the_fast_kernel():
+    """cmd/handlers/params.go:37-52: BlockSize 3..31 odd, MaxDisparity 16..256 step 16.  Planning
+    needs no GPU: every combination (and the defaults 16/64) must land on the column-wave kernel."""
+    for w, h in ((1920, 1080), (640, 480)):
+        assert capi.kernel_kind(w, h, 16, 64) == 1
+        for block in range(3, 32, 2):
+            for maxdisp in range(16, 257, 16):
+                assert capi.kernel_kind(w, h, block, maxdisp) == 1, (w, h, block, maxdisp)
+    assert capi.kernel_kind(1920, 1080, 33, 64) == 0             # BlockSize > 31: generic kernel
+    assert capi.kernel_kind(100, 100, 9, 96) == 0                # packed variant, frame narrower than D+2h+3
+    assert capi.kernel_kind(1920, 1080, 9, 64, capi.FLAG_FORCE_GENERIC) == 0

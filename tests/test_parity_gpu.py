@@ -203,6 +203,29 @@ def test_multi_pass_disparity_ranges(ctx):
     assert np.array_equal(ctx.disparity_region(L, R, 15, 240, reg), oracle.disparity_closed(L, R, 15, 240, region=reg))
 
 
+def test_large_blocks_two_lane_halo(ctx):
+    """BlockSize 18..31 (the UI goes to 31, cmd/handlers/params.go:37-44): windows wider than a
+    lane's 8 columns + one neighbour lane; unpacked sums, penalties up to 31 columns deep, and
+    the multi-pass split at 64 candidates."""
+    rng = np.random.default_rng(23)
+    for block in (18, 19, 21, 23, 25, 27, 29, 31):
+        hh = block // 2
+        hgt = 2 * hh + 4
+        for D, w in ((16, 150), (64, 200), (65, 200), (100, 230), (256, 330)):
+            assert capi.kernel_kind(w, hgt, block, D) == 1, (block, D)
+            Lr = rng.integers(0, 256, size=(hgt, w), dtype=np.uint8)
+            Rr = rng.integers(0, 256, size=(hgt, w), dtype=np.uint8)
+            Lx = np.full((hgt, w), 255, np.uint8); Rx = np.zeros((hgt, w), np.uint8); Rx[:, w // 2:] = 255
+            for name, (L, R) in (("random", (Lr, Rr)), ("extreme", (Lx, Rx))):
+                raw = D <= 255
+                got = ctx.disparity(L, R, block, D, capi.FLAG_RAW if raw else 0)
+                assert np.array_equal(got, _expect(L, R, block, D, raw=raw)), (name, block, D)
+    L, R = sha.synth.synth_pair(55, 1100, 90)                   # several tiles (480 output columns each) and strips
+    for block in (19, 31):
+        assert np.array_equal(ctx.disparity(L, R, block, 64), ctx.disparity(L, R, block, 64, capi.FLAG_FORCE_GENERIC))
+    assert capi.kernel_kind(640, 480, 33, 64) == 0                # beyond 31: the generic kernel
+
+
 def test_tall_frame_many_strips_and_tiles(ctx):
     """Strip seams (2h warm-up rows) and tile seams (halo lanes) on a frame taller/wider than any tile."""
     L, R = sha.synth.synth_pair(77, 1100, 700)
