@@ -144,6 +144,14 @@ def main():
                 and res["config"]["kernel_kind"] == 1:
             res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
             res["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, round %d)" % tj["round"]
+            if "sq_insts_valu_per_launch" in tj:
+                # the binding resource: vector-ALU issue slots.  Wave-instructions per launch from the
+                # PMC profile (SQ_INSTS_VALU) over the launch time measured here, against one issue per
+                # 4 cycles per SIMD (256 CUs x 4 SIMDs at the 2.4 GHz peak clock, MI355X_MICROARCH.md).
+                ginst = tj["sq_insts_valu_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
+                peak = 256 * 4 * 2.4 / 4
+                res["roofline"]["valu"] = {"achieved": ginst, "peak": peak, "unit": "G wave-instructions/s", "frac": ginst / peak,
+                                           "insts_per_launch": tj["sq_insts_valu_per_launch"]}
     except (OSError, KeyError, ValueError):
         pass
 
