@@ -626,7 +626,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int nsteps = (ye - ys) + 2 * H;
     int slot_in = 0;
     for (int t = 0; t < nsteps; ++t) {
-      if (t + 1 < nsteps) load_row(ys - H + t + 1);
+      // (also in the last step: one harmless row more keeps loads and landings unconditional)
+      load_row(ys - H + t + 1);
       const int so = slot_in + 2;                         // row t-(2h+1): NR - (2h+1) = 2 slots ahead
       const int slot_out = t > 2 * H ? (so >= NR ? so - NR : so) : NR;   // window not full yet: zero row
       const int sn = slot_in + 1 == NR ? 0 : slot_in + 1;
@@ -660,7 +661,12 @@ struct Cw {                                         // P columns per lane: 4 (h 
 #pragma unroll
         for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]);       // ds_min_u32
       }
-      if (t + 1 < nsteps) land_row(ring + sn * ROWW);
+      // One unconditional wait for the row loads (issued a whole update + reduce ago).  Left to
+      // itself hipcc waits inside each lane-masked store block of land_row and, unable to prove that
+      // one of them always runs, again at the loop head -- where vmcnt(0) also waits for the output
+      // bytes stored at the end of the previous step (a memory round trip per row and wave).
+      __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0); expcnt / lgkmcnt untouched
+      land_row(ring + sn * ROWW);
       if (t - 1 >= 2 * H) finalize(t - 1);
       wg_barrier();
       slot_in = sn;

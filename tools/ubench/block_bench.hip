@@ -12,8 +12,9 @@ __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
   using K = Cw<P, ND, H, PK>;
   constexpr int NC = K::NC;
   extern __shared__ __attribute__((aligned(16))) unsigned smem[];
-  unsigned C[P][NC]; int jlim[P]; unsigned best[P];
-  for (int p = 0; p < P; ++p) { jlim[p] = 100; best[p] = 0xffffffffu; for (int q = 0; q < NC; ++q) C[p][q] = io[(threadIdx.x * P + p) * NC + q] & 0xff00ff; }
+  unsigned C[P][NC]; unsigned long long M[K::NM]; unsigned best[P];
+  for (int k = 0; k < K::NM; ++k) M[k] = ~0ull;
+  for (int p = 0; p < P; ++p) { best[p] = 0xffffffffu; for (int q = 0; q < NC; ++q) C[p][q] = io[(threadIdx.x * P + p) * NC + q] & 0xff00ff; }
   for (int i = threadIdx.x; i < 8192; i += blockDim.x) smem[i] = io[i] & 0xff;
   __syncthreads();
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -26,8 +27,7 @@ __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
     if (MODE & 1) K::update_columns(C, l + so, r + so, l + so2, r + so2);
     slot = slot + 1 == 11 ? 0 : slot + 1;
     if (MODE & 32) { for (int p = 0; p < P; ++p) for (int q = 0; q < NC; ++q) C[p][q] += (unsigned)it & 1u; }   // defeat hoisting
-    if (MODE & 2) K::template reduce_row<0>(C, jlim, best, 0u, ND);
-    if (MODE & 4) K::template reduce_row<2>(C, jlim, best, 0u, ND);
+    if (MODE & 2) K::template reduce_row<0, 0>(C, M, best, 0u, ND);
     if (MODE & 2 || MODE & 4) { for (int p = 0; p < P; ++p) best[p] |= 0x80000000u; }   // keep the min chain from saturating
     if (MODE & 256) { unsigned* rb = smem + 7000 + (it & 1) * 256 + 4 * (threadIdx.x & 63); for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]); }
     if ((MODE & 64) && (it % BARK) == BARK - 1) __syncthreads();
@@ -60,18 +60,17 @@ void run(const char* name, int nw, int wgs_per_cu)
 
 int main()
 {
-  run<4, 12, 4, 3, true>("pk ND12 upd+red", 6, 4);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 6, 4);
-  run<4, 12, 4, 3 + 64, true, 2>("pk ND12 upd+red +barrier/2", 6, 4);
-  run<4, 12, 4, 3 + 64, true, 4>("pk ND12 upd+red +barrier/4", 6, 4);
-  run<4, 12, 4, 3 + 64, true, 16>("pk ND12 upd+red +barrier/16", 6, 4);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 4, 6);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 8, 3);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 12, 2);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 3, 8);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 2, 12);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 1, 24);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 5, 4);
-  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 7, 3);
+  // one workgroup per CU (config 5, BlockSize >= 16): does the per-row barrier cost issue slots?
+  run<4, 12, 4, 3, true>("pk ND12 upd+red", 16, 1);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 16, 1);
+  run<4, 12, 4, 3 + 64, true, 2>("pk ND12 upd+red +barrier/2", 16, 1);
+  run<4, 12, 4, 3 + 64, true, 4>("pk ND12 upd+red +barrier/4", 16, 1);
+  run<4, 12, 4, 3 + 64 + 128 + 256, true>("pk ND12 upd+red +all", 16, 1);
+  run<4, 12, 4, 3 + 64 + 128 + 256, true, 2>("pk ND12 upd+red +all, barrier/2", 16, 1);
+  run<4, 12, 4, 3, true>("pk ND12 upd+red", 8, 1);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 8, 1);
+  run<4, 12, 4, 3 + 64, true, 2>("pk ND12 upd+red +barrier/2", 8, 1);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 8, 2);
+  run<4, 12, 4, 3 + 64, true>("pk ND12 upd+red +barrier/1", 4, 5);
   return 0;
 }
