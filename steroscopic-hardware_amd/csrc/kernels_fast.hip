@@ -39,6 +39,7 @@
 //     cycles in the first version).
 #include "sadhip_kernels.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -188,7 +189,7 @@ __device__ __forceinline__ void wg_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int P, int ND, int H, bool PK>
+template <int P, int ND, int H, bool PK, bool W16 = false>
 struct Cw {                                         // P columns per lane: 4 (h <= 4) or 8 (h <= 15)
   // PK: column sums of disparity pairs packed as u16 halves (window SAD < 65536, i.e. h <= 7)
   static_assert(!PK || (H <= 7 && ND % 4 == 0), "packed sums need (2h+1)^2 * 255 < 65536");
@@ -205,28 +206,49 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static constexpr int NR = 2 * H + 3;              // ring rows: window + the leaving row + the landing row
   static constexpr int NRV = P + ND;                // R values a lane loads per row (last one unused)
   static constexpr int MAXL = P / 4;                // ring-row L elements per lane (>= 4 waves share a row)
-  static constexpr int MAXR = (TW + 4 * ND + 4 + 255) / 256;   // ... R elements per lane
+  // W16: ring pixels are u16 (two per dword) instead of u32 -- half the LDS per workgroup, one
+  // v_and / v_lshrrev more per operand.  For the variants whose ring (2h+4 rows of 1100 pixels)
+  // otherwise leaves room for one workgroup per CU: P = 8, h >= 7.
+  static_assert(!W16 || (P == 8 && ND == 8), "u16 ring: whole 16-byte reads need P and ND multiples of 8");
+  using Px = typename std::conditional<W16, unsigned short, unsigned>::type;
+  static constexpr int XOFF = W16 ? 7 : 3;          // dpad = nw*ND + XOFF keeps every lane's R operands 16-byte aligned
+  static constexpr int MAXR = (TW + 4 * ND + 8 + 255) / 256;   // ... R elements per lane
   static constexpr bool NEED_MASK = PK && H > 5;    // packed h = 6, 7: 2*(2h+1)^2*255 does not fit u16
   static constexpr int NM = ND + P;                 // lane masks: one per (candidate - column), see run()
 
+  // N ring pixels starting at a 16-byte aligned element -> one u32 register each.
+  template <int N>
+  static __device__ __forceinline__ void load_px(const Px* src, unsigned (&out)[N])
+  {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    if constexpr (W16) {
+      static_assert(N % 8 == 0, "");
+#pragma unroll
+      for (int m = 0; m < N / 8; ++m) {
+        const uint4 v = s4[m];
+        out[8 * m] = v.x & 0xffffu; out[8 * m + 1] = v.x >> 16; out[8 * m + 2] = v.y & 0xffffu; out[8 * m + 3] = v.y >> 16;
+        out[8 * m + 4] = v.z & 0xffffu; out[8 * m + 5] = v.z >> 16; out[8 * m + 6] = v.w & 0xffffu; out[8 * m + 7] = v.w >> 16;
+      }
+    } else {
+      static_assert(N % 4 == 0, "");
+#pragma unroll
+      for (int m = 0; m < N / 4; ++m) {
+        const uint4 v = s4[m];
+        out[4 * m] = v.x; out[4 * m + 1] = v.y; out[4 * m + 2] = v.z; out[4 * m + 3] = v.w;
+      }
+    }
+  }
+
   // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
-  // lin/lout: this lane's 4 L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
+  // lin/lout: this lane's P L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
   static __device__ __forceinline__ void update_columns(unsigned (&C)[P][NC],
-                                                        const uint4* lin, const uint4* rin,
-                                                        const uint4* lout, const uint4* rout)
+                                                        const Px* lin, const Px* rin,
+                                                        const Px* lout, const Px* rout)
   {
     {
       unsigned li[P], ri[NRV];
-#pragma unroll
-      for (int m = 0; m < P / 4; ++m) {
-        const uint4 l4 = lin[m];
-        li[4 * m] = l4.x; li[4 * m + 1] = l4.y; li[4 * m + 2] = l4.z; li[4 * m + 3] = l4.w;
-      }
-#pragma unroll
-      for (int m = 0; m < NRV / 4; ++m) {
-        const uint4 r4 = rin[m];
-        ri[4 * m] = r4.x; ri[4 * m + 1] = r4.y; ri[4 * m + 2] = r4.z; ri[4 * m + 3] = r4.w;
-      }
+      load_px(lin, li);
+      load_px(rin, ri);
       if constexpr (PK) {
 #pragma unroll
         for (int p = 0; p < P; ++p)
@@ -244,16 +266,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
     __builtin_amdgcn_sched_barrier(0);                    // keep the two operand sets from overlapping
     {
       unsigned lo[P], ro[NRV];
-#pragma unroll
-      for (int m = 0; m < P / 4; ++m) {
-        const uint4 l4 = lout[m];
-        lo[4 * m] = l4.x; lo[4 * m + 1] = l4.y; lo[4 * m + 2] = l4.z; lo[4 * m + 3] = l4.w;
-      }
-#pragma unroll
-      for (int m = 0; m < NRV / 4; ++m) {
-        const uint4 r4 = rout[m];
-        ro[4 * m] = r4.x; ro[4 * m + 1] = r4.y; ro[4 * m + 2] = r4.z; ro[4 * m + 3] = r4.w;
-      }
+      load_px(lout, lo);
+      load_px(rout, ro);
       if constexpr (PK) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -279,45 +293,30 @@ struct Cw {                                         // P columns per lane: 4 (h 
     }
   }
 
-  // The wave that owns the odd candidate dx = nw*ND (16k+1 candidates, see plan_for) slides its
-  // column sums here: lx/rx point at this lane's L pixels and at the 16-byte block holding R value
-  // x0 - dx - 3 (the lane's P values start at element 3).  Pixels are plain bytes (packed) or
-  // pre-shifted (unpacked): v_sad_u32 accumulates the right thing in both.
-  static __device__ __forceinline__ void extra_update(unsigned (&CX)[P][1], const uint4* lin, const uint4* rxin,
-                                                      const uint4* lout, const uint4* rxout)
+  // The wave that owns the odd candidate dx = nw*ND (16k+1 candidates, see plan_job) slides its
+  // column sums here: lin/rxin point at this lane's L pixels and at the 16-byte aligned block whose
+  // element XOFF is R column x0 - dx.  Pixels are plain bytes (packed) or pre-shifted (unpacked):
+  // v_sad_u32 accumulates the right thing in both.
+  static __device__ __forceinline__ void extra_update(unsigned (&CX)[P][1], const Px* lin, const Px* rxin,
+                                                      const Px* lout, const Px* rxout)
   {
+    constexpr int NX = W16 ? 16 : P + 4;                  // elements XOFF .. XOFF+P-1 are used
     {
-      unsigned li[P], ri[P + 4];
+      unsigned li[P], ri[NX];
+      load_px(lin, li);
+      load_px(rxin, ri);
 #pragma unroll
-      for (int m = 0; m < P / 4; ++m) {
-        const uint4 l4 = lin[m];
-        li[4 * m] = l4.x; li[4 * m + 1] = l4.y; li[4 * m + 2] = l4.z; li[4 * m + 3] = l4.w;
-      }
-#pragma unroll
-      for (int m = 0; m < P / 4 + 1; ++m) {
-        const uint4 r4 = rxin[m];
-        ri[4 * m] = r4.x; ri[4 * m + 1] = r4.y; ri[4 * m + 2] = r4.z; ri[4 * m + 3] = r4.w;
-      }
-#pragma unroll
-      for (int p = 0; p < P; ++p) sad_acc(CX[p][0], li[p], ri[p + 3]);
+      for (int p = 0; p < P; ++p) sad_acc(CX[p][0], li[p], ri[p + XOFF]);
     }
     __builtin_amdgcn_sched_barrier(0);
     {
-      unsigned lo[P], ro[P + 4];
-#pragma unroll
-      for (int m = 0; m < P / 4; ++m) {
-        const uint4 l4 = lout[m];
-        lo[4 * m] = l4.x; lo[4 * m + 1] = l4.y; lo[4 * m + 2] = l4.z; lo[4 * m + 3] = l4.w;
-      }
-#pragma unroll
-      for (int m = 0; m < P / 4 + 1; ++m) {
-        const uint4 r4 = rxout[m];
-        ro[4 * m] = r4.x; ro[4 * m + 1] = r4.y; ro[4 * m + 2] = r4.z; ro[4 * m + 3] = r4.w;
-      }
+      unsigned lo[P], ro[NX];
+      load_px(lout, lo);
+      load_px(rxout, ro);
 #pragma unroll
       for (int p = 0; p < P; p += 4)
         sad_sub4x(CX[p][0], CX[p + 1][0], CX[p + 2][0], CX[p + 3][0], lo[p], lo[p + 1], lo[p + 2], lo[p + 3],
-                  ro[p + 3], ro[p + 4], ro[p + 5], ro[p + 6]);
+                  ro[p + XOFF], ro[p + XOFF + 1], ro[p + XOFF + 2], ro[p + XOFF + 3]);
     }
   }
 
@@ -443,10 +442,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dcl = wv * ND;                              // first disparity of this wave within the pass
     const int dc = a.dbase + dcl;                         // ... and absolute
-    const int RW = TW + a.dpad + 1;                       // R values per ring row (multiple of 4)
-    const int ROWW = TW + RW;                             // u32 per ring row: L[TW] then R[RW]
-    unsigned* ring = smem;                                // (NR + 1) rows; row NR stays zero
-    unsigned* rowbest = smem + (NR + 1) * ROWW;           // [NB][TW]
+    const int RW = TW + a.dpad + 1;                       // R values per ring row (16 bytes' worth aligned)
+    const int ROWW = TW + RW;                             // pixels per ring row: L[TW] then R[RW]
+    Px* ring = reinterpret_cast<Px*>(smem);               // (NR + 1) rows; row NR stays zero
+    unsigned* rowbest = smem + (size_t)(NR + 1) * ROWW * sizeof(Px) / 4;   // [NB][TW]  (ROWW * sizeof(Px) is a multiple of 16)
     unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + NB * TW);  // [maxdisp+1]
 
     const int tile = blockIdx.x + a.tile0;
@@ -478,7 +477,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
         unsigned v = 0u;
         if (yy >= 0 && yy < j.h && col >= 0 && col < j.w)
           v = (unsigned)(isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride)[col];
-        ring[i] = v << a.pixshift;
+        ring[i] = (Px)(v << a.pixshift);
       }
     }
     __syncthreads();
@@ -515,13 +514,13 @@ struct Cw {                                         // P columns per lane: 4 (h 
         for (int v = 0; v < MAXR; ++v) pfr[v] = 0u;
       }
     };
-    auto land_row = [&](unsigned* dst) {
+    auto land_row = [&](Px* dst) {
 #pragma unroll
       for (int v = 0; v < MAXL; ++v)
-        if (lcol[v] != -2) dst[il0 + 64 * v] = PK ? pfl[v] : pfl[v] << a.pixshift;
+        if (lcol[v] != -2) dst[il0 + 64 * v] = (Px)(PK ? pfl[v] : pfl[v] << a.pixshift);
 #pragma unroll
       for (int v = 0; v < MAXR; ++v)
-        if (rcol[v] != -2) dst[TW + ir0 + 64 * v] = PK ? pfr[v] : pfr[v] << a.pixshift;
+        if (rcol[v] != -2) dst[TW + ir0 + 64 * v] = (Px)(PK ? pfr[v] : pfr[v] << a.pixshift);
     };
     const unsigned kmask = (1u << a.ksh) - 1u;
     auto finalize = [&](int t) {                          // output row of step t, this wave's pixels
@@ -611,10 +610,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // some pixel of this tile has d <= x-h < chunk end (exact plans: qn == ND)
     const bool key_mask = !use_pen && max(ox0, 0) - H < min(dc + ND - 1 + (xtra ? 1 : 0), j.maxdisp);
 
-    // this lane's operands inside a ring row (u32 index): L at lofs, R value m at rofs + m
+    // this lane's operands inside a ring row (pixel index): L at lofs, R value m at rofs + m
     const int lofs = P * lane;
-    const int rofs = TW + (a.dpad - dcl - (ND - 1)) + P * lane;       // multiple of 4 by construction
-    const int rxofs = TW + (a.dpad - a.nw * ND - 3) + P * lane;       // extra candidate: R value of column p at +3+p
+    const int rofs = TW + (a.dpad - dcl - (ND - 1)) + P * lane;       // 16-byte aligned by construction (dpad = nw*ND + XOFF)
+    const int rxofs = TW + (a.dpad - a.nw * ND - XOFF) + P * lane;    // extra candidate: R value of column p at +XOFF+p
 
     // ---- main loop: step t brings in image row ys-H+t (ring slot t % NR) ------------------------
     //   load    this wave's share of row t+1 (global -> registers; lands after the arithmetic)
@@ -631,17 +630,13 @@ struct Cw {                                         // P columns per lane: 4 (h 
       const int so = slot_in + 2;                         // row t-(2h+1): NR - (2h+1) = 2 slots ahead
       const int slot_out = t > 2 * H ? (so >= NR ? so - NR : so) : NR;   // window not full yet: zero row
       const int sn = slot_in + 1 == NR ? 0 : slot_in + 1;
-      const unsigned* rin = ring + slot_in * ROWW;
-      const unsigned* rout = ring + slot_out * ROWW;
-      const uint4* lin4 = reinterpret_cast<const uint4*>(rin + lofs);
-      const uint4* rin4 = reinterpret_cast<const uint4*>(rin + rofs);
-      const uint4* lout4 = reinterpret_cast<const uint4*>(rout + lofs);
-      const uint4* rout4 = reinterpret_cast<const uint4*>(rout + rofs);
+      const Px* rin = ring + slot_in * ROWW;
+      const Px* rout = ring + slot_out * ROWW;
       unsigned best[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
       const bool out_row = t >= 2 * H;
-      if (lane_valid) update_columns(C, lin4, rin4, lout4, rout4);
+      if (lane_valid) update_columns(C, rin + lofs, rin + rofs, rout + lofs, rout + rofs);
       if (out_row) {
         if (NEED_MASK && key_mask) reduce_row<2, 0>(C, M, best, (unsigned)dc, qn);
         else reduce_row<0, 0>(C, M, best, (unsigned)dc, qn);
@@ -649,8 +644,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
       if (xtra) {                                         // the odd candidate dx (wave-uniform branch)
         __builtin_amdgcn_sched_barrier(0);
         if (lane_valid)
-          extra_update(CX, lin4, reinterpret_cast<const uint4*>(rin + rxofs), lout4,
-                       reinterpret_cast<const uint4*>(rout + rxofs));
+          extra_update(CX, rin + lofs, rin + rxofs, rout + lofs, rout + rxofs);
         if (out_row) {
           if constexpr (NEED_MASK) reduce_row<2, ND>(CX, M, best, (unsigned)dx, 1);   // also drops the empty high half
           else reduce_row<0, 0>(CX, M, best, (unsigned)dx, 1);
@@ -677,10 +671,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
 
 
 // WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
-template <int P, int ND, int H, bool PK, int WB>
-__global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK>::run(a); }
+template <int P, int ND, int H, bool PK, int WB, bool W16>
+__global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK, W16>::run(a); }
 
-struct Plan { int p, nd, nw; bool pk, extra; };
+struct Plan { int p, nd, nw; bool pk, extra, w16; };
 struct Pass { Plan pl; int dbase; };              // candidates [dbase, dbase + nw*nd (+1)) of the job
 struct PassIo { int dbase; const unsigned* kin; unsigned* kout; int kw; };
 
@@ -700,7 +694,7 @@ int env_int(const char* name, int dflt)
 //   unpacked (h = 8; h = 6, 7 without an exact packed plan; SADHIP_TUNE_PK=0): P = 8, ND in {4, 8, 12}
 Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
 {
-  Plan best{0, 0, 0, false, false};
+  Plan best{0, 0, 0, false, false, false};
   const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aids: force a chunk size / wave count
   const int force_nw = env_int("SADHIP_TUNE_NW", 0);
   int p = (h <= 4 && pk) ? 4 : 8;
@@ -713,8 +707,12 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
       if (force_nw && force_nw != nw) continue;
       if (!pk && nd == 12 && nw > 8) continue;                  // unpacked ND 12 needs the 512-thread register budget
       if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
-      // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4] u32, two row buffers, the output LUT
-      if ((size_t)((2 * h + 4) * (2 * 64 * p + nw * nd + 4) + 2 * 64 * p) * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
+      // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated
+      // for packed h = 7 and unpacked h = 8, chunk size 8, <= 8 waves; unpacked pixels << bitlen(D) must fit)
+      const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
+                       ((pk && h == 7) || (!pk && h == 8 && maxdisp <= 255));
+      // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
+      if ((size_t)(2 * h + 4) * (2 * 64 * p + nw * nd + (w16 ? 8 : 4)) * (w16 ? 2 : 4) + (size_t)2 * 64 * p * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
       const int slots = nw * nd;
       if (slots + 1 < count) continue;
       const bool extra = slots + 1 == count;
@@ -722,7 +720,7 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
       if (!extra && slots - nd >= count && nw > 4) continue;    // a whole wave would be idle
       const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
       const long cost = (long)((nw + 3) / 4) * per_wave * 64 + nw;    // ties: fewer waves
-      if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra}; }
+      if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra, w16}; }
     }
   }
   return best;
@@ -762,10 +760,10 @@ std::vector<Pass> plan_job(int h, int maxdisp)
   return passes;
 }
 
-template <int P, int ND, int H, bool PK, int WB = 1024>
+template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false>
 hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s)
 {
-  using K = Cw<P, ND, H, PK>;
+  using K = Cw<P, ND, H, PK, W16>;
   CwArgs a{};
   a.j = j;
   a.nw = pl.nw;
@@ -774,7 +772,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   a.pixshift = PK ? 0 : a.ksh;
   a.nomask_pen = env_int("SADHIP_TUNE_NOPEN", 0);
   a.dbase = io.dbase; a.kin = io.kin; a.kout = io.kout; a.kw = io.kw;
-  a.dpad = pl.nw * ND + 3;                                    // == 3 (mod 4): lane operands 16-B aligned
+  a.dpad = pl.nw * ND + K::XOFF;                              // keeps every lane's R operands 16-byte aligned
   const int RW = K::TW + a.dpad + 1;
   a.shl = (K::TW + pl.nw - 1) / pl.nw;
   a.shr = (RW + pl.nw - 1) / pl.nw;
@@ -805,7 +803,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
   const int ROWW = K::TW + RW;
-  const size_t lds = (size_t)((K::NR + 1) * ROWW + K::NB * K::TW) * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
+  const size_t lds = (size_t)(K::NR + 1) * ROWW * sizeof(typename K::Px) + (size_t)K::NB * K::TW * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
                      + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
@@ -814,7 +812,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
     aa.j.left += (size_t)f0 * j.left_frame_stride;
     aa.j.right += (size_t)f0 * j.right_frame_stride;
     aa.j.out += (size_t)f0 * j.out_frame_stride;
-    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -836,6 +834,8 @@ bool fast_supported(const Job& j)
 static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s)
 {
   const int h = j.block / 2;
+  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s);
+  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s);   // 128-VGPR build: two workgroups per CU
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
   if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s)
 #define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_CASE(4, NDD, 4, true)
