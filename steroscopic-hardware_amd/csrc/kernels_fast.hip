@@ -710,7 +710,7 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
       // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated
       // for packed h = 7 and unpacked h = 8, chunk size 8, <= 8 waves; unpacked pixels << bitlen(D) must fit)
       const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
-                       ((pk && h == 7) || (!pk && h == 8 && maxdisp <= 255));
+                       ((pk && h == 7) || (!pk && h >= 8 && maxdisp <= 255));
       // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
       if ((size_t)(2 * h + 4) * (2 * 64 * p + nw * nd + (w16 ? 8 : 4)) * (w16 ? 2 : 4) + (size_t)2 * 64 * p * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
       const int slots = nw * nd;
@@ -836,6 +836,8 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   const int h = j.block / 2;
   if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s);
   if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s);   // 128-VGPR build: two workgroups per CU
+#define SADHIP_W16U(HH) if (pl.w16 && !pl.pk && h == HH) return launch_t<8, 8, HH, false, 1024, true>(j, pl, io, s)
+  SADHIP_W16U(9); SADHIP_W16U(10); SADHIP_W16U(11); SADHIP_W16U(12); SADHIP_W16U(13); SADHIP_W16U(14); SADHIP_W16U(15);
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
   if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s)
 #define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_CASE(4, NDD, 4, true)
