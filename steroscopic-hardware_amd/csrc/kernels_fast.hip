@@ -203,6 +203,12 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static constexpr int STEP = TW - 2 * OL;          // output columns per tile
   static constexpr int B1 = 2 * H + 1;              // window width
   static constexpr int NB = 2;                      // row-best buffers: one being filled, one being drained
+  // A row buffer holds the key of column p of lane l at p*RBP + l: the P ds_min_u32 of a wave then
+  // touch consecutive dwords (at l*P + p all 64 lanes hit 4 (P = 8) or 8 banks: 16-/8-way conflicts,
+  // two thirds of the LDS cycles of the P = 8 variants), and pitch 72 keeps the output pass, which
+  // walks the pixels in image order, at two-way.
+  static constexpr int RBP = 72;
+  static constexpr int RBW = P * RBP;               // u32 per row buffer
   static constexpr int NR = 2 * H + 3;              // ring rows: window + the leaving row + the landing row
   static constexpr int NRV = P + ND;                // R values a lane loads per row (last one unused)
   static constexpr int MAXL = P / 4;                // ring-row L elements per lane (>= 4 waves share a row)
@@ -445,8 +451,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int RW = TW + a.dpad + 1;                       // R values per ring row (16 bytes' worth aligned)
     const int ROWW = TW + RW;                             // pixels per ring row: L[TW] then R[RW]
     Px* ring = reinterpret_cast<Px*>(smem);               // (NR + 1) rows; row NR stays zero
-    unsigned* rowbest = smem + (size_t)(NR + 1) * ROWW * sizeof(Px) / 4;   // [NB][TW]  (ROWW * sizeof(Px) is a multiple of 16)
-    unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + NB * TW);  // [maxdisp+1]
+    unsigned* rowbest = smem + (size_t)(NR + 1) * ROWW * sizeof(Px) / 4;   // [NB][RBW]  (ROWW * sizeof(Px) is a multiple of 16)
+    unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + NB * RBW);  // [maxdisp+1]
 
     const int tile = blockIdx.x + a.tile0;
     const int tx = a.tx0 + tile * STEP;                   // image column of lane 0, p 0
@@ -466,7 +472,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // Ring row of image row yy: L columns [tx, tx+TW) then R columns [tx-dbase-dpad, tx-dbase+TW), one u32 per
     // pixel (shifted by ksh in the unpacked variant), zero outside the image.
     for (int i = tid; i < ROWW; i += nt) ring[NR * ROWW + i] = 0;
-    for (int i = tid; i < NB * TW; i += nt) rowbest[i] = KEY_INVALID;
+    for (int i = tid; i < NB * RBW; i += nt) rowbest[i] = KEY_INVALID;
     for (int i = tid; i <= j.maxdisp; i += nt)
       lut[i] = (unsigned char)(j.raw ? min(i, 255) : (i * 255) / j.maxdisp);     // sad.go:91-93
     {
@@ -525,15 +531,16 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const unsigned kmask = (1u << a.ksh) - 1u;
     auto finalize = [&](int t) {                          // output row of step t, this wave's pixels
       const int y = ys + t - 2 * H;
-      unsigned* rb = rowbest + (t & 1) * TW;
+      unsigned* rb = rowbest + (t & 1) * RBW;
       uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride;  // uniform base + 32-bit lane offset
       const size_t krow = ((size_t)f * (j.y1 - j.y0) + (y - j.y0)) * a.kw;
 #pragma unroll
       for (int v = 0; v < MAXL; ++v) {
         if (lcol[v] != -2) {
           const int i = il0 + 64 * v, x = tx + i;
-          unsigned k = rb[i];
-          rb[i] = KEY_INVALID;
+          const int ri = (i % P) * RBP + i / P;
+          unsigned k = rb[ri];
+          rb[ri] = KEY_INVALID;
           if (x >= ox0 && x < ox1) {
             if (a.kin) k = min(k, a.kin[krow + (unsigned)(x - j.x0)]);
             if (a.kout) {
@@ -651,9 +658,9 @@ struct Cw {                                         // P columns per lane: 4 (h 
         }
       }
       if (out_row) {
-        unsigned* rb = rowbest + (t & 1) * TW + lofs;
+        unsigned* rb = rowbest + (t & 1) * RBW + lane;
 #pragma unroll
-        for (int p = 0; p < P; ++p) atomicMin(rb + p, best[p]);       // ds_min_u32
+        for (int p = 0; p < P; ++p) atomicMin(rb + p * RBP, best[p]); // ds_min_u32
       }
       // One unconditional wait for the row loads (issued a whole update + reduce ago).  Left to
       // itself hipcc waits inside each lane-masked store block of land_row and, unable to prove that
@@ -712,7 +719,7 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
       const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
                        ((pk && h == 7) || (!pk && h >= 8 && maxdisp <= 255));
       // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
-      if ((size_t)(2 * h + 4) * (2 * 64 * p + nw * nd + (w16 ? 8 : 4)) * (w16 ? 2 : 4) + (size_t)2 * 64 * p * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
+      if ((size_t)(2 * h + 4) * (2 * 64 * p + nw * nd + (w16 ? 8 : 4)) * (w16 ? 2 : 4) + (size_t)2 * 72 * p * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
       const int slots = nw * nd;
       if (slots + 1 < count) continue;
       const bool extra = slots + 1 == count;
@@ -742,7 +749,7 @@ std::vector<Pass> plan_job(int h, int maxdisp)
     if (!pk && ((long long)b1 * b1 * 255 << ksh) >= (1LL << 27)) break;
     const bool exact = pk && h > 5;
     // full passes: 16 waves of ND 16 (P 4) / ND 8 (P 8); two-lane halos: 8 waves of ND 8
-    const int chunk = (h <= 4 && pk) ? 256 : (h <= 8 ? 128 : 64);
+    const int chunk = env_int("SADHIP_TUNE_CHUNK", (h <= 4 && pk) ? 256 : (h <= 8 ? 128 : 64));
     passes.clear();
     int base = 0, rem = maxdisp + 1;
     while (rem > 0) {
@@ -803,7 +810,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
   const int ROWW = K::TW + RW;
-  const size_t lds = (size_t)(K::NR + 1) * ROWW * sizeof(typename K::Px) + (size_t)K::NB * K::TW * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
+  const size_t lds = (size_t)(K::NR + 1) * ROWW * sizeof(typename K::Px) + (size_t)K::NB * K::RBW * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
                      + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   for (int f0 = 0; f0 < j.n; f0 += 32768) {

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc ${PMC:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS} --output-format csv -d $OUT -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/log.txt 2>&1
 echo "exit=$?"
 python3 - <<PY
 import csv, glob, collections
