@@ -161,9 +161,15 @@ SADHIP_API int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
  * pkg/camera/output.go:200-204): device time of the kernel(s) and wall time incl. copies. */
 SADHIP_API int sadhip_last_timing(sadhip_ctx* ctx, float* kernel_ms, float* total_ms);
 
-/* Which kernel a given parameter set dispatches to: 0 = generic, 1 = packed-u16 fast kernel.
- * (diagnostics / tests) */
+/* Which kernel a given parameter set dispatches to: 0 = generic, 1 = column-wave fast kernel.
+ * (diagnostics / tests; needs no GPU) */
 SADHIP_API int sadhip_kernel_kind(int w, int h, int block, int maxdisp, unsigned flags);
+
+/* How the fast kernel would run a parameter set (diagnostics / tests; needs no GPU): writes one
+ * line per pass, "dbase=<first candidate> count=<candidates> p=<columns per lane> nd=<chunk> nw=<waves>
+ * packed=<0|1> extra=<0|1> w16=<0|1> lds=<bytes>", into buf (NUL-terminated, truncated to cap).
+ * Returns the number of passes, 0 when the generic kernel would run, -1 on invalid parameters. */
+SADHIP_API int sadhip_plan_describe(int w, int h, int block, int maxdisp, char* buf, int cap);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ SYMBOLS = {
                                            C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int]),
     "sadhip_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sadhip_kernel_kind": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "sadhip_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
 }
 
 _LIB = None
@@ -132,6 +133,16 @@ def device_count():
 
 def kernel_kind(w, h, block, maxdisp, flags=0):
     return lib().sadhip_kernel_kind(w, h, block, maxdisp, flags)
+
+
+def plan_describe(w, h, block, maxdisp):
+    """The passes the column-wave kernel would run (no GPU needed): list of dicts with the integer
+    fields dbase, count, p, nd, nw, packed, extra, w16, lds; [] when the generic kernel would run."""
+    buf = C.create_string_buffer(16384)
+    n = lib().sadhip_plan_describe(w, h, block, maxdisp, buf, len(buf))
+    if n < 0:
+        raise SadHipError(ERR_ARG, "invalid parameters")
+    return [{k: int(v) for k, v in (f.split("=") for f in line.split())} for line in buf.value.decode().splitlines()]
 
 
 def _img(a, name):

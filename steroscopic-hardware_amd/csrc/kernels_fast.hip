@@ -838,6 +838,25 @@ bool fast_supported(const Job& j)
   return true;
 }
 
+int describe_fast(const Job& j, char* buf, int cap)
+{
+  if (buf && cap > 0) buf[0] = 0;
+  if (!fast_supported(j)) return 0;
+  const int h = j.block / 2;
+  const std::vector<Pass> passes = plan_job(h, j.maxdisp);
+  int at = 0;
+  for (size_t k = 0; k < passes.size(); ++k) {
+    const Plan& pl = passes[k].pl;
+    const int next = k + 1 < passes.size() ? passes[k + 1].dbase : j.maxdisp + 1;
+    const size_t lds = (size_t)(2 * h + 4) * (2 * 64 * pl.p + pl.nw * pl.nd + (pl.w16 ? 8 : 4)) * (pl.w16 ? 2 : 4) +
+                       (size_t)2 * 72 * pl.p * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15);
+    if (buf && at < cap)
+      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d lds=%zu\n",
+                     passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, lds);
+  }
+  return (int)passes.size();
+}
+
 static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s)
 {
   const int h = j.block / 2;

@@ -215,6 +215,15 @@ static hipError_t dispatch(const Job& j, unsigned flags, hipStream_t s)
   return launch_generic(j, s);
 }
 
+extern "C" int sadhip_plan_describe(int w, int h, int block, int maxdisp, char* buf, int cap)
+{
+  if (buf && cap > 0) buf[0] = 0;
+  if (check_params(w, h, w, w, block, maxdisp) != SADHIP_OK) return -1;
+  Job j{}; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp; j.n = 1;
+  j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.lstride = j.rstride = j.ostride = w;
+  return describe_fast(j, buf, cap);
+}
+
 extern "C" int sadhip_kernel_kind(int w, int h, int block, int maxdisp, unsigned flags)
 {
   if (check_params(w, h, w, w, block, maxdisp) != SADHIP_OK) return -1;

@@ -37,6 +37,8 @@ hipError_t launch_mirror(const Job& j, int mode, hipStream_t s);
 // Fast kernel (kernels_fast.hip): returns true if it supports the job's parameters.
 bool fast_supported(const Job& j);
 hipError_t launch_fast(const Job& j, hipStream_t s);
+// Text description of the passes launch_fast would run (empty when it would not): see sadhip_plan_describe.
+int describe_fast(const Job& j, char* buf, int cap);
 
 // Single-window SADs, literal clamps of sad.go:205-244.
 hipError_t launch_sad_windows(const uint8_t* left, int lw, int lh, int lstride,

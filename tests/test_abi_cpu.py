@@ -104,3 +104,40 @@ def test_whole_ui_parameter_grid_plans_on_the_fast_kernel():
     assert capi.kernel_kind(1920, 1080, 33, 64) == 0             # BlockSize > 31: generic kernel
     assert capi.kernel_kind(100, 100, 9, 96) == 0                # packed variant, frame narrower than D+2h+3
     assert capi.kernel_kind(1920, 1080, 9, 64, capi.FLAG_FORCE_GENERIC) == 0
+
+
+def test_planner_invariants_over_the_parameter_space():
+    """plan_job (kernels_fast.hip) through sadhip_plan_describe: passes tile [0, D] without gaps, stay
+    inside the launch limits the kernel assumes, and keep the properties the kernel relies on."""
+    seen = set()
+    for block in range(2, 32):
+        hh = block // 2
+        for maxdisp in list(range(1, 70)) + [95, 96, 100, 127, 128, 129, 160, 192, 193, 200, 255, 256, 257, 300, 511, 512, 1000, 4096]:
+            w = max(1920, maxdisp + 2 * hh + 40)
+            plan = capi.plan_describe(w, 64, block, maxdisp)
+            assert (len(plan) > 0) == (capi.kernel_kind(w, 64, block, maxdisp) == 1)
+            at = 0
+            for i, ps in enumerate(plan):
+                assert ps["dbase"] == at and ps["count"] >= 1
+                at += ps["count"]
+                slots = ps["nw"] * ps["nd"]
+                assert 4 <= ps["nw"] <= 16 and ps["nd"] % 4 == 0 and ps["p"] in (4, 8)
+                assert ps["lds"] <= 160 * 1024
+                assert ps["extra"] == (1 if slots + 1 == ps["count"] else 0)
+                assert slots + ps["extra"] >= ps["count"]
+                if i + 1 < len(plan):
+                    assert slots == ps["count"] and ps["extra"] == 0       # full passes are exact
+                if ps["packed"]:
+                    assert hh <= 7 and ps["p"] == (4 if hh <= 4 else 8)
+                    if hh > 5:
+                        assert slots + ps["extra"] == ps["count"]           # lane-mask variants: exact plans only
+                else:
+                    assert hh >= 3 and ps["p"] == 8
+                    assert ((2 * hh + 1) ** 2 * 255 << maxdisp.bit_length()) < (1 << 27)
+                if ps["w16"]:
+                    assert ps["p"] == 8 and ps["nd"] == 8 and ps["nw"] <= 8 and (ps["packed"] or maxdisp <= 255)
+                seen.add((ps["p"], ps["nd"], ps["packed"], ps["w16"]))
+            assert at in (0, maxdisp + 1)
+    assert {(4, 16, 1, 0), (8, 8, 1, 1), (8, 8, 0, 1), (8, 12, 1, 0), (8, 4, 0, 0)} <= seen
+    assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0,
+                                                         lds=capi.plan_describe(1920, 1080, 9, 64)[0]["lds"])]
