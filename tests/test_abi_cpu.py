@@ -141,3 +141,13 @@ def test_planner_invariants_over_the_parameter_space():
     assert {(4, 16, 1, 0), (8, 8, 1, 1), (8, 8, 0, 1), (8, 12, 1, 0), (8, 4, 0, 0)} <= seen
     assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0,
                                                          lds=capi.plan_describe(1920, 1080, 9, 64)[0]["lds"])]
+
+
+def test_block_microbenchmark_still_compiles_against_the_kernel():
+    """tools/ubench/block_bench.hip includes kernels_fast.hip and calls its blocks directly;
+    __graft_entry__.build() compiles it, so an interface change in the kernel must not break it."""
+    import subprocess
+    src = os.path.join(REPO, "tools", "ubench", "block_bench.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "--cuda-device-only", "-c",
+                        "-Wno-unused-command-line-argument", "-o", os.devnull, src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -18,12 +18,12 @@ __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
   for (int i = threadIdx.x; i < 8192; i += blockDim.x) smem[i] = io[i] & 0xff;
   __syncthreads();
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint4* l = reinterpret_cast<const uint4*>(smem + 4 * (threadIdx.x & 63));
-  const uint4* r = reinterpret_cast<const uint4*>(smem + 256 + 12 * wv + 4 * (threadIdx.x & 63));
+  const unsigned* l = smem + 4 * (threadIdx.x & 63);
+  const unsigned* r = smem + 256 + 12 * wv + 4 * (threadIdx.x & 63);
   int slot = 0;
   for (int it = 0; it < iters; ++it) {
-    const int so = (MODE & 128) ? slot * 146 : 0;                    // ring rows of 584 dwords = 146 uint4
-    const int so2 = (MODE & 128) ? ((slot + 2) % 11) * 146 : 64;
+    const int so = (MODE & 128) ? slot * 584 : 0;                    // ring rows of 584 dwords
+    const int so2 = (MODE & 128) ? ((slot + 2) % 11) * 584 : 256;
     if (MODE & 1) K::update_columns(C, l + so, r + so, l + so2, r + so2);
     slot = slot + 1 == 11 ? 0 : slot + 1;
     if (MODE & 32) { for (int p = 0; p < P; ++p) for (int q = 0; q < NC; ++q) C[p][q] += (unsigned)it & 1u; }   // defeat hoisting
