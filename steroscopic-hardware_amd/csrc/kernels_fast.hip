@@ -36,7 +36,15 @@
 //     ND is a multiple of 4 and the R part of a ring row is offset so that every
 //     lane's operands are 16-byte aligned: all operand reads are ds_read_b128, bank-conflict free
 //     at a lane stride of 16 bytes (ds_read_b32 at that stride was a 4-way conflict: 72 % of LDS
-//     cycles in the first version).
+//     cycles in the first version).  Variants whose u32 ring would leave room for one workgroup
+//     per CU only keep u16 pixels instead (W16).
+//   * missing candidates (d > x-h at the left image edge, d > D in a ragged last chunk) are removed
+//     by the START VALUES of the column sums (penalties that survive the sliding updates), not by
+//     masking keys row after row; packed h = 6, 7, where a penalty does not fit u16, masks keys
+//     with 64-bit lane masks held in SGPRs (one v_cndmask_b32 per key, leftmost tile only).
+//   * BlockSize 18..31: the window reaches into the lane after the neighbour (two DPP hops).
+//   * D+1 beyond 16 waves' worth: several launches over candidate ranges, a u32 key per pixel
+//     travelling between them (plan_job / launch_fast at the end of this file).
 #include "sadhip_kernels.h"
 #include <algorithm>
 #include <type_traits>
