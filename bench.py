@@ -31,6 +31,37 @@ W, H, BLOCK, MAXDISP = 1920, 1080, 9, 64
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _time_reference_c(ctx, sha):
+    import subprocess
+    import tempfile
+    import numpy as np
+    exe = os.path.join(REPO, "oracle", "_ref", "sad_ref")
+    fx = os.path.join(REPO, "tests", "golden", "hardware_fixtures.npz")
+    if not (os.path.exists(exe) and os.path.exists(fx)):
+        return None
+    d = np.load(fx)
+    L, R, exp = d["patch_L"][1], d["patch_R"][1], d["exp_disp_sadc"]
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            os.mkdir(os.path.join(td, "mems"))
+            L.tofile(os.path.join(td, "mems", "img_L_patch_1.raw")); R.tofile(os.path.join(td, "mems", "img_R_patch_1.raw"))
+            t0 = time.perf_counter()
+            subprocess.check_call([exe], cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=60)
+            cpu_s = time.perf_counter() - t0
+            got = np.array([int(x, 16) for x in open(os.path.join(td, "exp_disp.mem")).read().split()], np.uint8).reshape(128, 128)
+        gpu = ctx.disparity(L, R, 15, 64, sha.capi.FLAG_MIRROR_SADC)          # warm-up + check
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.disparity(L, R, 15, 64, sha.capi.FLAG_MIRROR_SADC)
+        gpu_s = (time.perf_counter() - t0) / 20
+        return {"workload": "hardware/sad.c unmodified (oracle/_ref/sad_ref): 128x128 patch 1, WIN 15, D 64, incl. its file I/O, 1 core",
+                "cpu_seconds": cpu_s, "cpu_matches_committed_fixture": bool(np.array_equal(got, exp)),
+                "gpu_seconds_host_fed": gpu_s, "gpu_matches": bool(np.array_equal(gpu, exp)),
+                "note": "same semantics on the GPU through SADHIP_FLAG_MIRROR_SADC (host buffers, synchronous call)"}
+    except Exception as e:                                        # never fail the bench over the side measurement
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +187,12 @@ def main():
         pass
 
     if not args.no_cpu_baseline:
+        # the reference's own C (hardware/sad.c, compiled unmodified into oracle/_ref/ in the build
+        # container) on its own fixed workload, next to the GPU running the same semantics: not the
+        # metric's workload, so reported beside cpu_baseline, not as it
+        ref_c = _time_reference_c(ctx, sha)
+        if ref_c:
+            res["reference_c"] = ref_c
         import oracle
         nthr = args.cpu_threads or min(16, os.cpu_count() or 1)
         L0, R0 = Ls[0].cpu().numpy(), Rs[0].cpu().numpy()
