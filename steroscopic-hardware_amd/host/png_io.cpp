@@ -87,6 +87,9 @@ bool decode_png(const uint8_t* data, size_t n, PngImage& out, std::string* err)
   const size_t bpp_bits = (size_t)nch * depth;
   const size_t row_bytes = ((size_t)w * bpp_bits + 7) / 8;
   const size_t fbpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;          // filter byte distance
+  // deflate expands at most ~1032:1: a header that promises more than the IDAT bytes can hold is
+  // rejected before anything of that size is allocated
+  if ((row_bytes + 1) * (size_t)h > idat.size() * 1100 + 65536) return fail(err, "zlib stream does not match the image size");
   std::vector<uint8_t> raw((row_bytes + 1) * (size_t)h);
   uLongf raw_len = (uLongf)raw.size();
   const int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
