@@ -186,7 +186,7 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract)
         # the reference's own C (hardware/sad.c, compiled unmodified into oracle/_ref/ in the build
         # container) on its own fixed workload, next to the GPU running the same semantics: not the
         # metric's workload, so reported beside cpu_baseline, not as it
