@@ -50,6 +50,7 @@
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace sadhip {
@@ -693,9 +694,25 @@ struct Plan { int p, nd, nw; bool pk, extra, w16; };
 struct Pass { Plan pl; int dbase; };              // candidates [dbase, dbase + nw*nd (+1)) of the job
 struct PassIo { int dbase; const unsigned* kin; unsigned* kout; int kw; };
 
+// Tuning aids (diagnostics; tools/README.md).  The environment is read once per process: a launch
+// consults these a few hundred times while planning.
 int env_int(const char* name, int dflt)
 {
-  const char* e = getenv(name);
+  struct Entry { const char* name; int value; bool set; };
+  static const auto table = [] {
+    static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
+                                        "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_NOPEN", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
+                                        "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE"};
+    std::vector<Entry> t;
+    for (const char* n : names) {
+      const char* e = getenv(n);
+      t.push_back(Entry{n, e ? atoi(e) : 0, e != nullptr});
+    }
+    return t;
+  }();
+  for (const Entry& e : table)
+    if (e.name == name || strcmp(e.name, name) == 0) return e.set ? e.value : dflt;
+  const char* e = getenv(name);                                 // not in the table: read it live
   return e ? atoi(e) : dflt;
 }
 
@@ -745,7 +762,18 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
 // of a workgroup -- as several passes of 16 full waves plus a last pass for the rest (see CwArgs).
 // Packed first; unpacked when the window SAD does not fit 16 bits (h = 8), when forced, or when a
 // packed h = 6, 7 kernel has no exact plan.  Empty result: the generic kernel runs the job.
+std::vector<Pass> plan_job_uncached(int h, int maxdisp);
+
+// plan_job with a one-entry memo per thread: a caller streams frames with the same two parameters.
 std::vector<Pass> plan_job(int h, int maxdisp)
+{
+  thread_local int memo_h = -1, memo_d = -1;
+  thread_local std::vector<Pass> memo;
+  if (h != memo_h || maxdisp != memo_d) { memo = plan_job_uncached(h, maxdisp); memo_h = h; memo_d = maxdisp; }
+  return memo;
+}
+
+std::vector<Pass> plan_job_uncached(int h, int maxdisp)
 {
   std::vector<Pass> passes;
   if (h < 1 || h > 15 || maxdisp < 1) return passes;
