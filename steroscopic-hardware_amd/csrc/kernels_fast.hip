@@ -738,6 +738,7 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
     for (int nw = 4; nw <= 16; ++nw) {
       if (force_nw && force_nw != nw) continue;
       if (!pk && nd == 12 && nw > 8) continue;                  // unpacked ND 12 needs the 512-thread register budget
+      if (p == 4 && nw > 8) continue;                           // measured: 11-16 waves (one workgroup per CU) lose ~10 % to passes of 8 waves
       if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
       // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated
       // for packed h = 7 and unpacked h = 8, chunk size 8, <= 8 waves; unpacked pixels << bitlen(D) must fit)
@@ -784,8 +785,8 @@ std::vector<Pass> plan_job_uncached(int h, int maxdisp)
     const int b1 = 2 * h + 1, ksh = 32 - __builtin_clz((unsigned)maxdisp);
     if (!pk && ((long long)b1 * b1 * 255 << ksh) >= (1LL << 27)) break;
     const bool exact = pk && h > 5;
-    // full passes: 16 waves of ND 16 (P 4) / ND 8 (P 8); two-lane halos: 8 waves of ND 8
-    const int chunk = env_int("SADHIP_TUNE_CHUNK", (h <= 4 && pk) ? 256 : (h <= 8 ? 128 : 64));
+    // full passes: 8 waves of ND 16 (P 4) / 16 waves of ND 8 (P 8); two-lane halos: 8 waves of ND 8
+    const int chunk = env_int("SADHIP_TUNE_CHUNK", h <= 8 ? 128 : 64);
     passes.clear();
     int base = 0, rem = maxdisp + 1;
     while (rem > 0) {
