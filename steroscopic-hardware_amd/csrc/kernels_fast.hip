@@ -759,8 +759,9 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
   return best;
 }
 
-// The whole disparity range [0, D] as one pass, or -- when D+1 candidates do not fit the 16 waves
-// of a workgroup -- as several passes of 16 full waves plus a last pass for the rest (see CwArgs).
+// The whole disparity range [0, D] as one pass, or -- when D+1 candidates do not fit the waves a
+// workgroup may have -- as several full passes of `chunk` candidates plus a last pass for the rest
+// (see CwArgs).
 // Packed first; unpacked when the window SAD does not fit 16 bits (h = 8), when forced, or when a
 // packed h = 6, 7 kernel has no exact plan.  Empty result: the generic kernel runs the job.
 std::vector<Pass> plan_job_uncached(int h, int maxdisp);
