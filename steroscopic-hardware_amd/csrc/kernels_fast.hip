@@ -732,12 +732,14 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
   int p = (h <= 4 && pk) ? 4 : 8;
   if (env_int("SADHIP_TUNE_P", 0) == 8) p = 8;                  // tuning aid: 8 columns per lane for h <= 4 too
   long best_cost = 1L << 60;
-  const int nd_max = p == 4 ? 24 : ((!pk && h != 8) ? 8 : 12);   // instantiated chunk sizes (unpacked ND 12: h = 8 only)
+  // chunk sizes: P = 4 up to 24; P = 8 up to 12 for the penalty variants (packed h = 5), 8 otherwise --
+  // measured: the lane-mask variants spill at ND 12 (B15 D48: 47 vs 36 us) and the unpacked ones
+  // lose their u16 ring (B16 D48: 41 vs 37 us)
+  const int nd_max = p == 4 ? 24 : ((pk && h <= 5) ? 12 : 8);
   for (int nd = 4; nd <= nd_max; nd += 4) {
     if (force_nd && force_nd != nd) continue;
     for (int nw = 4; nw <= 16; ++nw) {
       if (force_nw && force_nw != nw) continue;
-      if (!pk && nd == 12 && nw > 8) continue;                  // unpacked ND 12 needs the 512-thread register budget
       if (p == 4 && nw > 8) continue;                           // measured: 11-16 waves (one workgroup per CU) lose ~10 % to passes of 8 waves
       if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
       // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated
@@ -907,13 +909,13 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
 #define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_CASE(4, NDD, 4, true)
 #define SADHIP_P8(NDD) SADHIP_CASE(8, NDD, 5, true); SADHIP_CASE(8, NDD, 6, true); SADHIP_CASE(8, NDD, 7, true)
   SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
-  SADHIP_P8(4); SADHIP_P8(8); SADHIP_P8(12);
+  SADHIP_P8(4); SADHIP_P8(8); SADHIP_CASE(8, 12, 5, true);
   SADHIP_CASE(8, 8, 4, true); SADHIP_CASE(8, 12, 4, true);     // forced for comparison (SADHIP_TUNE_P=8)
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
 #define SADHIP_U(HH, NDD) \
   if (pl.p == 8 && pl.nd == NDD && h == HH && !pl.pk) \
     return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, io, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, io, s)
-  SADHIP_U(8, 4); SADHIP_U(8, 8); SADHIP_U(8, 12);
+  SADHIP_U(8, 4); SADHIP_U(8, 8);
   SADHIP_U(7, 4); SADHIP_U(7, 8); SADHIP_U(6, 4); SADHIP_U(6, 8);   // D without an exact packed plan
 #define SADHIP_UH(HH) SADHIP_U(HH, 4); if (pl.p == 8 && pl.nd == 8 && h == HH && !pl.pk) return launch_t<8, 8, HH, false, 512>(j, pl, io, s)
   SADHIP_UH(9); SADHIP_UH(10); SADHIP_UH(11); SADHIP_UH(12); SADHIP_UH(13); SADHIP_UH(14); SADHIP_UH(15);   // BlockSize 18..31: two-lane halos
