@@ -766,22 +766,27 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
 // (see CwArgs).
 // Packed first; unpacked when the window SAD does not fit 16 bits (h = 8), when forced, or when a
 // packed h = 6, 7 kernel has no exact plan.  Empty result: the generic kernel runs the job.
-std::vector<Pass> plan_job_uncached(int h, int maxdisp);
+// narrow: the frame is at most D + 2h + 2 wide -- a right-clipped window of a packed variant could
+// meet a missing candidate without its penalty column, so only the unpacked variants (every column
+// penalised) may run.
+std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow);
 
-// plan_job with a one-entry memo per thread: a caller streams frames with the same two parameters.
-std::vector<Pass> plan_job(int h, int maxdisp)
+// plan_job with a one-entry memo per thread: a caller streams frames with the same parameters.
+std::vector<Pass> plan_job(int h, int maxdisp, bool narrow)
 {
-  thread_local int memo_h = -1, memo_d = -1;
+  thread_local int memo_h = -1, memo_d = -1, memo_n = -1;
   thread_local std::vector<Pass> memo;
-  if (h != memo_h || maxdisp != memo_d) { memo = plan_job_uncached(h, maxdisp); memo_h = h; memo_d = maxdisp; }
+  if (h != memo_h || maxdisp != memo_d || (int)narrow != memo_n) {
+    memo = plan_job_uncached(h, maxdisp, narrow); memo_h = h; memo_d = maxdisp; memo_n = narrow;
+  }
   return memo;
 }
 
-std::vector<Pass> plan_job_uncached(int h, int maxdisp)
+std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
 {
   std::vector<Pass> passes;
   if (h < 1 || h > 15 || maxdisp < 1) return passes;
-  for (int variant = (h <= 7 && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; variant < 2; ++variant) {
+  for (int variant = (h <= 7 && !narrow && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; variant < 2; ++variant) {
     const bool pk = variant == 0;
     if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
     // unpacked keys ((2h+1)^2*255 << bitlen(D)) must stay below the 2^27 penalty
@@ -871,11 +876,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
 bool fast_supported(const Job& j)
 {
   if (j.w < 1 || j.h < 1) return false;
-  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp);   // BlockSize 2..31
-  if (passes.empty()) return false;
-  // packed sums: a right-clipped window could meet a missing candidate without its penalty column
-  if (passes[0].pl.pk && j.w <= j.maxdisp + 2 * (j.block / 2) + 2) return false;
-  return true;
+  return !plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2).empty();   // BlockSize 2..31
 }
 
 int describe_fast(const Job& j, char* buf, int cap)
@@ -883,7 +884,7 @@ int describe_fast(const Job& j, char* buf, int cap)
   if (buf && cap > 0) buf[0] = 0;
   if (!fast_supported(j)) return 0;
   const int h = j.block / 2;
-  const std::vector<Pass> passes = plan_job(h, j.maxdisp);
+  const std::vector<Pass> passes = plan_job(h, j.maxdisp, j.w <= j.maxdisp + 2 * h + 2);
   int at = 0;
   for (size_t k = 0; k < passes.size(); ++k) {
     const Plan& pl = passes[k].pl;
@@ -917,9 +918,9 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
     return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, io, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, io, s)
   SADHIP_U(8, 4); SADHIP_U(8, 8);
   SADHIP_U(7, 4); SADHIP_U(7, 8); SADHIP_U(6, 4); SADHIP_U(6, 8);   // D without an exact packed plan
+  SADHIP_U(5, 4); SADHIP_U(5, 8); SADHIP_U(4, 4); SADHIP_U(4, 8); SADHIP_U(3, 4); SADHIP_U(3, 8);   // narrow frames
 #define SADHIP_UH(HH) SADHIP_U(HH, 4); if (pl.p == 8 && pl.nd == 8 && h == HH && !pl.pk) return launch_t<8, 8, HH, false, 512>(j, pl, io, s)
   SADHIP_UH(9); SADHIP_UH(10); SADHIP_UH(11); SADHIP_UH(12); SADHIP_UH(13); SADHIP_UH(14); SADHIP_UH(15);   // BlockSize 18..31: two-lane halos
-  SADHIP_CASE(8, 8, 4, false); SADHIP_CASE(8, 8, 3, false);           // forced for comparison (SADHIP_TUNE_PK=0)
 #undef SADHIP_CASE
   return hipErrorInvalidValue;
 }
@@ -928,7 +929,7 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
 {
   if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
   if (!fast_supported(j)) return launch_generic(j, s);
-  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp);
+  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2);
   if (passes.size() == 1) {
     const hipError_t e = launch_pass(j, passes[0].pl, PassIo{0, nullptr, nullptr, 0}, s);
     return e == hipErrorInvalidValue ? launch_generic(j, s) : e;

@@ -102,7 +102,9 @@ def test_whole_ui_parameter_grid_plans_on_the_fast_kernel():
             for maxdisp in range(16, 257, 16):
                 assert capi.kernel_kind(w, h, block, maxdisp) == 1, (w, h, block, maxdisp)
     assert capi.kernel_kind(1920, 1080, 33, 64) == 0             # BlockSize > 31: generic kernel
-    assert capi.kernel_kind(100, 100, 9, 96) == 0                # packed variant, frame narrower than D+2h+3
+    assert capi.kernel_kind(100, 100, 9, 96) == 1                # frame narrower than D+2h+3: the unpacked variant
+    assert all(not ps["packed"] for ps in capi.plan_describe(100, 100, 9, 96))
+    assert capi.kernel_kind(100, 100, 3, 96) == 0                # ... which does not exist for BlockSize < 6
     assert capi.kernel_kind(1920, 1080, 9, 64, capi.FLAG_FORCE_GENERIC) == 0
 
 
