@@ -580,7 +580,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
     //             is >= the worst d = 0 sum and <= 2*PEN, which fits 16 bits for h <= 5.
     // Windows clipped on the left (x <= h) only have d = 0 and are forced to lut[0] at the output;
     // packed windows clipped on the right can meet missing candidates only when w <= D + 2h + 2:
-    // launch_fast() sends those frames to the generic kernel.  Packed h = 6, 7 (NEED_MASK) masks
+    // plan_job() gives those frames the unpacked variant.  Packed h = 6, 7 (NEED_MASK) masks
     // keys instead: candidate j of the wave is valid for column p of lane l iff
     // tx + P*l + p - h >= dc + j, i.e. l >= ceil((dc + h - tx + (j - p)) / P): one 64-bit lane mask
     // per value of j - p, kept in SGPRs and applied with one v_cndmask_b32 per key.
