@@ -22,7 +22,15 @@
  *
  * Threading: a context may be used from any OS thread (every call selects the context's HIP
  * device itself -- goroutines migrate between threads); calls on one context are serialised
- * by an internal mutex.  Host pointers are never retained after a call returns (cgo rule).
+ * by an internal mutex.  Destroying a context while another thread is inside a call on it is a
+ * use-after-free like in any C API: the bindings in INTEGRATION.md hold a reader lock across each
+ * call.  Host pointers are never retained after a call returns, error returns included (cgo rule):
+ * host buffers are copied with 2-D copies straight from / to the caller's memory on the context's
+ * stream, and every host-buffer entry point waits for that stream before it returns.
+ * sadhip_last_error() is thread-local: read it on the OS thread that made the failing call (a Go
+ * caller wraps call + read in runtime.LockOSThread).
+ * The library reads no environment variable (tuning knobs exist only in the diagnostics build
+ * lib/libsadhip_tune.so used by tools/).
  */
 #ifndef SADHIP_H
 #define SADHIP_H
@@ -34,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SADHIP_ABI_VERSION 1
+#define SADHIP_ABI_VERSION 2   /* 2: flag validation, MIRROR_VERILOG, sadhip_last_kernel_kind, sadhip_pool_* */
 
 #if defined(__GNUC__)
 #define SADHIP_API __attribute__((visibility("default")))
@@ -50,23 +58,29 @@ extern "C" {
 #define SADHIP_ERR_BLOCK        4   /* block < 1 or block > SADHIP_MAX_BLOCK */
 #define SADHIP_ERR_MAXDISP      5   /* maxdisp < 1 (the reference divides by zero) or > SADHIP_MAX_MAXDISP */
 #define SADHIP_ERR_REGION       6   /* region not inside [0,w) x [0,h) or empty/inverted */
-#define SADHIP_ERR_BATCH        7   /* n < 0 or n larger than the context's batch capacity */
+#define SADHIP_ERR_BATCH        7   /* n < 0 (a batch may be of any length), or max_batch < 1 at context creation */
 #define SADHIP_ERR_NO_DEVICE    8   /* no HIP device / bad device ordinal */
 #define SADHIP_ERR_HIP          9   /* a HIP runtime call failed; see sadhip_last_error() */
-#define SADHIP_ERR_ARG         10   /* any other invalid argument */
+#define SADHIP_ERR_ARG         10   /* any other invalid argument: unknown flag bits, two mirror modes at once, ... */
 #define SADHIP_ERR_NOMEM       11   /* host or device allocation failed */
 
 #define SADHIP_MAX_BLOCK     255
 #define SADHIP_MAX_MAXDISP  4096
 
-/* sadhip_disparity_* "flags" argument */
+/* sadhip_disparity_* "flags" argument.  Bits not defined here, or more than one MIRROR_* bit,
+ * are rejected with SADHIP_ERR_ARG. */
 #define SADHIP_FLAG_RAW        1u   /* store best d itself (clamped to 255) instead of best*255/maxdisp */
 #define SADHIP_FLAG_FORCE_GENERIC 2u /* diagnostics: use the generic kernel even where the fast one applies */
 /* Hardware-mirror modes: compute with the semantics of the reference's OTHER golden models instead
  * of pkg/despair's, raw d output, so the FPGA testbench fixtures can be regenerated at any size
- * (SURVEY.md section 8 f-4).  Mutually exclusive; block = the models' WIN, maxdisp = MAX_DISP. */
+ * (SURVEY.md section 8 f-4, a-10).  Mutually exclusive; block = the models' WIN, maxdisp = MAX_DISP. */
 #define SADHIP_FLAG_MIRROR_SADC   4u /* hardware/sad.c:66-106 (interior only, xr<0 terms skipped) */
 #define SADHIP_FLAG_MIRROR_TESTPY 8u /* hardware/test.py:262-294 compute_disparity_patch (zero padding) */
+#define SADHIP_FLAG_MIRROR_VERILOG 16u /* hardware/compute_SAD.v:62-265 compute_max_disp: the right window slides to
+                                        * LARGER columns (:213), d in [0, maxdisp) EXCLUSIVE (:206-215) and only while the
+                                        * window stays inside the image, strict '<' (:201-204), interior pixels only
+                                        * (border 0); a WIN-row strip of the testbenches (ez_tb.v) gives its result at
+                                        * (x, y) = (col_index + WIN/2, WIN/2) */
 
 typedef struct sadhip_ctx sadhip_ctx;   /* opaque per-device context */
 
@@ -78,9 +92,10 @@ SADHIP_API const char* sadhip_last_error(void);                  /* thread-local
 
 /* ---- context ------------------------------------------------------------------------------
  * Replaces the worker pool of SetupConcurrentSAD (pkg/despair/sad.go:29-113): one context owns
- * the device buffers, pinned staging and HIP streams for frames up to max_w x max_h and batches
- * of up to max_batch frames.  Created when the Go shim's pipeline is set up, destroyed when its
- * input channel is closed (sad.go:106-110, pkg/camera/output.go:213-220). */
+ * the device planes (two frame slots), scratch and HIP streams for frames up to max_w x max_h.
+ * max_batch (>= 1) is a sizing hint kept for ABI stability: batches of ANY length stream through
+ * the two slots.  Created when the Go shim's pipeline is set up, destroyed when its input channel
+ * is closed (sad.go:106-110, pkg/camera/output.go:213-220). */
 SADHIP_API int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch, sadhip_ctx** out);
 SADHIP_API int sadhip_ctx_destroy(sadhip_ctx* ctx);
 SADHIP_API int sadhip_ctx_device(const sadhip_ctx* ctx, int* device);
@@ -110,7 +125,8 @@ SADHIP_API int sadhip_disparity_region_u8(sadhip_ctx* ctx,
 
 /* ---- batch of independent frames, host buffers (synchronous; pipelined inside) --------------
  * Replaces the streaming loop of examples/run.stream.go:30-59 / BASELINE config 4: n independent
- * pairs, H2D / kernel / D2H double-buffered on the context's streams through pinned staging. */
+ * pairs (any n >= 0), H2D / kernel / D2H double-buffered on the context's two streams; copies go
+ * straight from / to the caller's buffers (2-D copies), nothing is retained after return. */
 SADHIP_API int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
                               const uint8_t* const* lefts, const uint8_t* const* rights,
                               int w, int h, int lstride, int rstride,
@@ -150,7 +166,9 @@ SADHIP_API int sadhip_sad_windows_u8(sadhip_ctx* ctx,
 SADHIP_API int sadhip_gray_u8(sadhip_ctx* ctx, const uint8_t* pix, int channels,
                    int w, int h, int stride, uint8_t* gray, int gstride);
 
-/* RGBA/RGB pair in, disparity out: gray conversion fused in front of the SAD kernel on device. */
+/* RGBA/RGB pair in, disparity out: ONE upload per image (2-D copy from the caller's rows), gray
+ * conversion on the device into the context's planes, disparity kernel, one download -- no host
+ * gray plane, no second H2D (what LoadPNG + RunSad cost separately). */
 SADHIP_API int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
                              const uint8_t* left_pix, const uint8_t* right_pix, int channels,
                              int w, int h, int lstride, int rstride,
@@ -161,15 +179,40 @@ SADHIP_API int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
  * pkg/camera/output.go:200-204): device time of the kernel(s) and wall time incl. copies. */
 SADHIP_API int sadhip_last_timing(sadhip_ctx* ctx, float* kernel_ms, float* total_ms);
 
-/* Which kernel a given parameter set dispatches to: 0 = generic, 1 = column-wave fast kernel.
- * (diagnostics / tests; needs no GPU) */
+/* Which kernel a given parameter set dispatches to (diagnostics / tests; needs no GPU):
+ * 0 = generic, 1 = column-wave fast kernel, 2 / 3 / 4 = the sad.c / test.py / compute_SAD.v mirror
+ * kernels; -1 on invalid parameters or flags.  The answer is binding: a job planned for the
+ * column-wave kernel either runs on it or fails with SADHIP_ERR_HIP -- there is no silent fallback. */
 SADHIP_API int sadhip_kernel_kind(int w, int h, int block, int maxdisp, unsigned flags);
+
+/* Which kernel the LAST successful disparity call of the calling thread actually launched (same
+ * numbering; -1 before any call).  Tests and bench.py assert it equals sadhip_kernel_kind(). */
+SADHIP_API int sadhip_last_kernel_kind(void);
 
 /* How the fast kernel would run a parameter set (diagnostics / tests; needs no GPU): writes one
  * line per pass, "dbase=<first candidate> count=<candidates> p=<columns per lane> nd=<chunk> nw=<waves>
  * packed=<0|1> extra=<0|1> w16=<0|1> lds=<bytes>", into buf (NUL-terminated, truncated to cap).
  * Returns the number of passes, 0 when the generic kernel would run, -1 on invalid parameters. */
 SADHIP_API int sadhip_plan_describe(int w, int h, int block, int maxdisp, char* buf, int cap);
+
+/* ---- multi-device pool (host buffers, synchronous) -------------------------------------------
+ * Replaces, for a host with several GPUs, the streaming loop of examples/run.stream.go:30-59 at
+ * BASELINE config 4's shape: one context and one host thread per entry of devices[] (an ordinal may
+ * be listed more than once: several contexts on one GPU), frame i of a batch runs on entry
+ * i mod n_devices, the two parameters are fanned out by the host, results land in outs[i].  There is
+ * no device-to-device exchange on this path.  One batch at a time per pool; the calling thread
+ * blocks until every device has finished (on failure too: no caller pointer stays in use). */
+typedef struct sadhip_pool sadhip_pool;
+SADHIP_API int sadhip_pool_create(const int* devices, int n_devices, int max_w, int max_h, sadhip_pool** out);
+SADHIP_API int sadhip_pool_destroy(sadhip_pool* pool);
+SADHIP_API int sadhip_pool_size(const sadhip_pool* pool, int* n_devices);
+SADHIP_API int sadhip_pool_batch_u8(sadhip_pool* pool, int n,
+                         const uint8_t* const* lefts, const uint8_t* const* rights,
+                         int w, int h, int lstride, int rstride,
+                         int block, int maxdisp, unsigned flags,
+                         uint8_t* const* outs, int ostride);
+/* kernel_ms_sum: device time of the kernels summed over the pool's devices; wall_ms: of the call */
+SADHIP_API int sadhip_pool_last_timing(sadhip_pool* pool, float* kernel_ms_sum, float* wall_ms);
 
 #ifdef __cplusplus
 }

@@ -331,6 +331,30 @@ ORACLE_API int oracle_mirror_verilog_strip(const uint8_t *L, const uint8_t *R,
     return best;
 }
 
+/* The same search for every interior pixel of an image (what SADHIP_FLAG_MIRROR_VERILOG computes):  */
+/* pixel (x,y) = the strip of rows [y-m, y+m] with col_index = x-m; candidates d in [0, ndisp) whose */
+/* right window [x-m+d, x+m+d] stays inside the image (compute_SAD.v:206-215); border pixels 0.      */
+ORACLE_API void oracle_mirror_verilog(const uint8_t *L, const uint8_t *R, int w, int h,
+                                      int win, int ndisp, uint8_t *out)
+{
+    int m = win / 2;
+    memset(out, 0, (size_t)w * h);
+    for (int y = m; y < h - m; y++)
+        for (int x = m; x < w - m; x++) {
+            int best = 0, bests = INT_MAX;
+            for (int d = 0; d < ndisp && x + m + d < w; d++) {
+                int s = 0;
+                for (int dy = -m; dy <= m; dy++)
+                    for (int dx = -m; dx <= m; dx++) {
+                        int a = L[(y + dy) * w + x + dx], b = R[(y + dy) * w + x + dx + d];   /* :213 */
+                        s += a >= b ? a - b : b - a;
+                    }
+                if (s < bests) { bests = s; best = d; }                                    /* :201-204 */
+            }
+            out[y * w + x] = (uint8_t)(best > 255 ? 255 : best);
+        }
+}
+
 /* ------------------------------------------------------------------------ */
 /* Synthetic stereo pair generator of SURVEY.md section 8(d) (splitmix64).    */
 /* Test/bench input only; the product never generates frames.                 */

@@ -127,6 +127,14 @@ def mirror_verilog_strip(L, R, win, ndisp):
     return d, ms.value
 
 
+def mirror_verilog(L, R, win, ndisp):
+    """compute_SAD.v's strip search for every interior pixel (border 0), raw d."""
+    L = np.ascontiguousarray(L); R = np.ascontiguousarray(R)
+    out = np.zeros_like(L)
+    lib().oracle_mirror_verilog(_p(L), _p(R), L.shape[1], L.shape[0], win, ndisp, _p(out))
+    return out
+
+
 def synth_pair(seed, w, h):
     L = np.zeros((h, w), np.uint8); R = np.zeros((h, w), np.uint8)
     lib().oracle_synth_pair(C.c_uint64(seed), w, h, _p(L), _p(R))

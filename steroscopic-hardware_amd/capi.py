@@ -23,6 +23,9 @@ FLAG_RAW = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_MIRROR_SADC = 4
 FLAG_MIRROR_TESTPY = 8
+FLAG_MIRROR_VERILOG = 16
+KIND_GENERIC, KIND_COLWAVE, KIND_MIRROR_SADC, KIND_MIRROR_TESTPY, KIND_MIRROR_VERILOG = range(5)
+ABI_VERSION = 2
 MAX_BLOCK = 255
 MAX_MAXDISP = 4096
 
@@ -55,7 +58,15 @@ SYMBOLS = {
                                            C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int]),
     "sadhip_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sadhip_kernel_kind": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "sadhip_last_kernel_kind": (C.c_int, []),
     "sadhip_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "sadhip_pool_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sadhip_pool_destroy": (C.c_int, [C.c_void_p]),
+    "sadhip_pool_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "sadhip_pool_batch_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
+                                       C.POINTER(C.c_void_p), C.c_int]),
+    "sadhip_pool_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
 _LIB = None
@@ -116,6 +127,8 @@ def lib():
             fn = getattr(l, name)          # AttributeError if the ABI symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if l.sadhip_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {l.sadhip_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
         _LIB = l
     return _LIB
 
@@ -133,6 +146,11 @@ def device_count():
 
 def kernel_kind(w, h, block, maxdisp, flags=0):
     return lib().sadhip_kernel_kind(w, h, block, maxdisp, flags)
+
+
+def last_kernel_kind():
+    """Kernel the calling thread's last successful disparity call actually launched (KIND_*; -1: none)."""
+    return lib().sadhip_last_kernel_kind()
 
 
 def plan_describe(w, h, block, maxdisp):
@@ -274,3 +292,69 @@ class Context:
                                              d_left.stride(1), d_right.stride(1), block, maxdisp, flags,
                                              d_out.data_ptr(), d_out.stride(0), d_out.stride(1), stream))
         return d_out
+
+
+def _frames(lefts, rights, outs):
+    """Checks one batch of equally shaped u8 frames; returns (n, w, h, ls, rs, outs, pointer arrays)."""
+    n = len(lefts)
+    assert len(rights) == n
+    h, w = lefts[0].shape
+    ls, rs = lefts[0].strides[0], rights[0].strides[0]
+    for a in list(lefts) + list(rights):
+        _img(a, "frame")
+        assert a.shape == (h, w)
+    assert all(a.strides[0] == ls for a in lefts) and all(a.strides[0] == rs for a in rights)
+    if outs is None:
+        outs = [np.empty((h, w), np.uint8) for _ in range(n)]
+    assert len(outs) == n and all(o.shape == (h, w) and o.strides == (w, 1) for o in outs)
+    pa = (C.c_void_p * n)(*[a.ctypes.data for a in lefts])
+    pb = (C.c_void_p * n)(*[a.ctypes.data for a in rights])
+    po = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
+    return n, w, h, ls, rs, outs, pa, pb, po
+
+
+class Pool:
+    """sadhip_pool: one context + host thread per entry of ``devices`` (an ordinal may repeat);
+    frame i of a batch runs on entry i mod len(devices)."""
+
+    def __init__(self, devices, max_w=1920, max_h=1080):
+        devices = list(devices)
+        self._h = C.c_void_p()
+        arr = (C.c_int * max(len(devices), 1))(*devices)
+        _check(lib().sadhip_pool_create(arr, len(devices), max_w, max_h, C.byref(self._h)))
+        self.devices = devices
+
+    def close(self):
+        if self._h:
+            lib().sadhip_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        n = C.c_int(0)
+        _check(lib().sadhip_pool_size(self._h, C.byref(n)))
+        return n.value
+
+    def batch(self, lefts, rights, block, maxdisp, flags=0, outs=None):
+        if len(lefts) == 0:
+            _check(lib().sadhip_pool_batch_u8(self._h, 0, None, None, 1, 1, 1, 1, block, maxdisp, flags, None, 1))
+            return []
+        n, w, h, ls, rs, outs, pa, pb, po = _frames(lefts, rights, outs)
+        _check(lib().sadhip_pool_batch_u8(self._h, n, pa, pb, w, h, ls, rs, block, maxdisp, flags, po, w))
+        return outs
+
+    def last_timing(self):
+        k, t = C.c_float(0), C.c_float(0)
+        _check(lib().sadhip_pool_last_timing(self._h, C.byref(k), C.byref(t)))
+        return k.value, t.value

@@ -68,7 +68,6 @@ struct CwArgs {
   int tile0;       // first tile index launched (blockIdx.x + tile0)
   int th;          // output rows per strip
   int shl, shr;    // per-wave share of a ring row: L elements (= output pixels), R elements
-  int nomask_pen;  // tuning aid: 2 = penalty initialisation even where it is not exact (timing only)
   // Disparity ranges wider than one workgroup can hold run as several passes (launches) over
   // candidates [dbase, dbase + nw*ND (+1)): a pass merges its per-pixel keys with the keys of the
   // passes before it (kin) and hands them on (kout); the last pass writes the u8 output.
@@ -186,6 +185,15 @@ __device__ __forceinline__ unsigned sel_lanes(unsigned long long mask, unsigned 
   unsigned r;
   asm("v_cndmask_b32 %0, -1, %1, %2" : "=v"(r) : "v"(key), "s"(mask));
   return r;
+}
+// lanes >= l0 keep the key (l0 >= 64: none).  The mask is built from l0 at the use (two scalar
+// instructions on the otherwise idle scalar unit): holding NM ready-made 64-bit masks cost 2*NM SGPRs
+// and spilled 13-15 of them in the packed h = 6, 7 variants.
+__device__ __forceinline__ unsigned sel_from(int l0, unsigned key)
+{
+  asm volatile("" : "+s"(l0));                          // keeps the mask from being hoisted out of the row loop again
+  const unsigned long long mask = l0 < 64 ? (~0ull << l0) : 0ull;
+  return sel_lanes(mask, key);
 }
 
 // Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also emits
@@ -364,7 +372,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // runs past MaxDisparity); the extra candidate's empty high half is dropped here (qn = 1).
   // JOFS = index of the array's first candidate within the wave (0; ND for the extra candidate).
   template <int MASK, int JOFS>
-  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const unsigned long long (&M)[NM],
+  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const int (&M)[NM],
                                                  unsigned (&best)[P], unsigned dbase, int qn)
   {
     // window sum of column p = own columns + last (h-p) columns of the left lane + first (p+h-P+1)
@@ -417,8 +425,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
         unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
         if (MASK == 2) {
           const int ie = JOFS + 2 * q - p + P - 1, io = ie + 1;
-          ke = sel_lanes(M[ie < NM ? ie : NM - 1], ke);
-          ko = (JOFS != 0 && 2 * q + 1 >= qn) ? KEY_INVALID : sel_lanes(M[io < NM ? io : NM - 1], ko);
+          ke = sel_from(M[ie < NM ? ie : NM - 1], ke);
+          ko = (JOFS != 0 && 2 * q + 1 >= qn) ? KEY_INVALID : sel_from(M[io < NM ? io : NM - 1], ko);
         }
         const unsigned m = ke < ko ? ke : ko;
         best[p] = m < best[p] ? m : best[p];                      // v_min3_u32
@@ -426,7 +434,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
         unsigned k = s[p];
         if (MASK == 2) {
           const int i = JOFS + q - p + P - 1;
-          k = sel_lanes(M[i < NM ? i : NM - 1], k);
+          k = sel_from(M[i < NM ? i : NM - 1], k);
         }
         best[p] = k < best[p] ? k : best[p];
       }
@@ -434,7 +442,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
   }
 
   template <int MASK, int JOFS, int W>
-  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const unsigned long long (&M)[NM],
+  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const int (&M)[NM],
                                                     unsigned (&best)[P], unsigned dbase, int qn)
   {
 #pragma unroll
@@ -504,18 +512,27 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // column, range-checked by the hardware against the row width -- columns left or right of the
     // image (and NOT_MINE, as unsigned) read as 0 without branches or address arithmetic.
     constexpr int NOT_MINE = (int)0x80000000;
-    const int il0 = wv * a.shl + lane, ir0 = wv * a.shr + lane;
+    int il0, ir0;
     int lcol[MAXL], rcol[MAXR];
+    auto row_share = [&](int ln) {                        // ln = lane
+      il0 = wv * a.shl + ln; ir0 = wv * a.shr + ln;
 #pragma unroll
-    for (int v = 0; v < MAXL; ++v) {
-      const int i = il0 + 64 * v;
-      lcol[v] = (lane + 64 * v < a.shl && i < TW) ? tx + i : NOT_MINE;
-    }
+      for (int v = 0; v < MAXL; ++v) {
+        const int i = il0 + 64 * v;
+        lcol[v] = (ln + 64 * v < a.shl && i < TW) ? tx + i : NOT_MINE;
+      }
 #pragma unroll
-    for (int v = 0; v < MAXR; ++v) {
-      const int i = ir0 + 64 * v;
-      rcol[v] = (lane + 64 * v < a.shr && i < RW) ? tx - a.dbase - a.dpad + i : NOT_MINE;
-    }
+      for (int v = 0; v < MAXR; ++v) {
+        const int i = ir0 + 64 * v;
+        rcol[v] = (ln + 64 * v < a.shr && i < RW) ? tx - a.dbase - a.dpad + i : NOT_MINE;
+      }
+    };
+    row_share(lane);
+    // The unpacked variants run at their 128-register limit: there these loop-invariant per-lane
+    // values are recomputed in every step from a lane id the compiler cannot see through (a dozen
+    // VALU instructions per step) instead of being held -- held, they were spilled to scratch in the
+    // set-up code and reloaded in every step (14-21 VGPRs, 60-88 bytes of scratch per lane).
+    constexpr bool RECOMPUTE_SHARE = !PK;
     unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
     auto load_row = [&](int yy) {
       if (yy >= 0 && yy < j.h) {
@@ -600,13 +617,13 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // tx + P*l + p - h >= dc + j, i.e. l >= ceil((dc + h - tx + (j - p)) / P): one 64-bit lane mask
     // per value of j - p, kept in SGPRs and applied with one v_cndmask_b32 per key.
     constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
-    const bool use_pen = !NEED_MASK || a.nomask_pen == 2;
-    unsigned long long M[NM];
+    constexpr bool use_pen = !NEED_MASK;
+    int M[NM];                                          // first lane whose key survives, per value of j - p (64: none)
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
       const int t = dc + H - tx + (k - (P - 1)) + P - 1;  // ceil(num / P) = floor((num + P-1) / P)
       const int l0 = t > 0 ? t / P : 0;
-      M[k] = (NEED_MASK && l0 < 64) ? (~0ull << l0) : 0ull;
+      M[k] = (NEED_MASK && l0 < 64) ? l0 : 64;
     }
     // Candidates d > D (a chunk that runs past MaxDisparity) exist for no pixel: same trick with the
     // class c == w-1 (mod 2h+1), 0 <= c < w, which every window has exactly once -- also the windows
@@ -656,6 +673,11 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const int nsteps = (ye - ys) + 2 * H;
     int slot_in = 0;
     for (int t = 0; t < nsteps; ++t) {
+      if constexpr (RECOMPUTE_SHARE) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        row_share(ln);
+      }
       // (also in the last step: one harmless row more keeps loads and landings unconditional)
       load_row(ys - H + t + 1);
       const int so = slot_in + 2;                         // row t-(2h+1): NR - (2h+1) = 2 slots ahead
@@ -709,15 +731,19 @@ struct Plan { int p, nd, nw; bool pk, extra, w16; };
 struct Pass { Plan pl; int dbase; };              // candidates [dbase, dbase + nw*nd (+1)) of the job
 struct PassIo { int dbase; const unsigned* kin; unsigned* kout; int kw; };
 
-// Tuning aids (diagnostics; tools/README.md).  The environment is read once per process: a launch
-// consults these a few hundred times while planning.
+// Tuning aids.  The product build (libsadhip.so) reads NO environment variable: env_int() is the
+// constant default there, so a stray variable in the host process cannot change a plan.  The
+// diagnostics build (-DSADHIP_TUNING -> lib/libsadhip_tune.so, loaded by tools/ only) reads
+// SADHIP_TUNE_* once per process (a launch consults them a few hundred times while planning).
+#ifdef SADHIP_TUNING
 int env_int(const char* name, int dflt)
 {
   struct Entry { const char* name; int value; bool set; };
   static const auto table = [] {
     static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
-                                        "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_NOPEN", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
-                                        "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE"};
+                                        "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
+                                        "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
+                                        "SADHIP_TUNE_FCOL"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -730,6 +756,9 @@ int env_int(const char* name, int dflt)
   const char* e = getenv(name);                                 // not in the table: read it live
   return e ? atoi(e) : dflt;
 }
+#else
+constexpr int env_int(const char*, int dflt) { return dflt; }
+#endif
 
 // Kernel variant for `count` consecutive candidates: columns per lane P, packed or not, chunk size
 // ND, wave count NW and whether the last wave carries one extra candidate (NW*ND + 1 == count, the
@@ -827,8 +856,11 @@ std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
   return passes;
 }
 
+// dry: run every host-side check (instantiation exists, per-wave shares fit, LDS fits) and return
+// without launching -- what fast_supported() asks, so that a job the column-wave kernel cannot run
+// is routed to the generic kernel at PLANNING time and never by a silent fallback after a failure.
 template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false>
-hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s)
+hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry)
 {
   using K = Cw<P, ND, H, PK, W16>;
   CwArgs a{};
@@ -837,7 +869,6 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   a.xw = pl.extra ? pl.nw - 1 : -1;
   a.ksh = PK ? 16 : 32 - __builtin_clz((unsigned)j.maxdisp);  // unpacked: 2^ksh > maxdisp
   a.pixshift = PK ? 0 : a.ksh;
-  a.nomask_pen = env_int("SADHIP_TUNE_NOPEN", 0);
   a.dbase = io.dbase; a.kin = io.kin; a.kout = io.kout; a.kw = io.kw;
   a.dpad = pl.nw * ND + K::XOFF;                              // keeps every lane's R operands 16-byte aligned
   const int RW = K::TW + a.dpad + 1;
@@ -873,12 +904,16 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   const size_t lds = (size_t)(K::NR + 1) * ROWW * sizeof(typename K::Px) + (size_t)K::NB * K::RBW * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
                      + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (dry) return hipSuccess;
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     CwArgs aa = a;
     aa.j.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
     aa.j.left += (size_t)f0 * j.left_frame_stride;
     aa.j.right += (size_t)f0 * j.right_frame_stride;
     aa.j.out += (size_t)f0 * j.out_frame_stride;
+    const size_t koff = (size_t)f0 * (size_t)rows * (size_t)a.kw;      // the kernel indexes keys with its local frame number
+    if (aa.kin) aa.kin += koff;
+    if (aa.kout) aa.kout += koff;
     hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -888,10 +923,14 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
 
 }  // namespace
 
+// plan exists AND every pass of it is a kernel this build instantiates and can launch
+static bool passes_launchable(const Job& j, const std::vector<Pass>& passes);
+
 bool fast_supported(const Job& j)
 {
   if (j.w < 1 || j.h < 1) return false;
-  return !plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2).empty();   // BlockSize 2..31
+  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2);   // BlockSize 2..31
+  return !passes.empty() && passes_launchable(j, passes);
 }
 
 int describe_fast(const Job& j, char* buf, int cap)
@@ -913,15 +952,24 @@ int describe_fast(const Job& j, char* buf, int cap)
   return (int)passes.size();
 }
 
-static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s)
+static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry = false)
 {
   const int h = j.block / 2;
-  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s);
-  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s);   // 128-VGPR build: two workgroups per CU
-#define SADHIP_W16U(HH) if (pl.w16 && !pl.pk && h == HH) return launch_t<8, 8, HH, false, 1024, true>(j, pl, io, s)
+#ifdef SADHIP_EXPERIMENT        // resource-usage experiments: only the instantiations under study (seconds to compile)
+  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry);
+  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry);
+  if (pl.w16 && !pl.pk && h == 15) return launch_t<8, 8, 15, false, 1024, true>(j, pl, io, s, dry);
+  if (pl.p == 8 && pl.nd == 8 && h == 7 && pl.pk) return launch_t<8, 8, 7, true>(j, pl, io, s, dry);
+  if (pl.p == 8 && pl.nd == 8 && h == 5 && !pl.pk) return launch_t<8, 8, 5, false, 1024>(j, pl, io, s, dry);
+  if (pl.p == 4 && pl.nd == 16 && h == 4 && pl.pk) return launch_t<4, 16, 4, true>(j, pl, io, s, dry);
+  return hipErrorInvalidValue;
+#else
+  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry);
+  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry);   // 128-VGPR build: two workgroups per CU
+#define SADHIP_W16U(HH) if (pl.w16 && !pl.pk && h == HH) return launch_t<8, 8, HH, false, 1024, true>(j, pl, io, s, dry)
   SADHIP_W16U(9); SADHIP_W16U(10); SADHIP_W16U(11); SADHIP_W16U(12); SADHIP_W16U(13); SADHIP_W16U(14); SADHIP_W16U(15);
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
-  if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s)
+  if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s, dry)
 #define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_CASE(4, NDD, 4, true)
 #define SADHIP_P8(NDD) SADHIP_CASE(8, NDD, 5, true); SADHIP_CASE(8, NDD, 6, true); SADHIP_CASE(8, NDD, 7, true)
   SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
@@ -930,16 +978,30 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
 #define SADHIP_U(HH, NDD) \
   if (pl.p == 8 && pl.nd == NDD && h == HH && !pl.pk) \
-    return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, io, s) : launch_t<8, NDD, HH, false, 1024>(j, pl, io, s)
+    return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, io, s, dry) : launch_t<8, NDD, HH, false, 1024>(j, pl, io, s, dry)
   SADHIP_U(8, 4); SADHIP_U(8, 8);
   SADHIP_U(7, 4); SADHIP_U(7, 8); SADHIP_U(6, 4); SADHIP_U(6, 8);   // D without an exact packed plan
   SADHIP_U(5, 4); SADHIP_U(5, 8); SADHIP_U(4, 4); SADHIP_U(4, 8); SADHIP_U(3, 4); SADHIP_U(3, 8);   // narrow frames
-#define SADHIP_UH(HH) SADHIP_U(HH, 4); if (pl.p == 8 && pl.nd == 8 && h == HH && !pl.pk) return launch_t<8, 8, HH, false, 512>(j, pl, io, s)
+#define SADHIP_UH(HH) SADHIP_U(HH, 4); if (pl.p == 8 && pl.nd == 8 && h == HH && !pl.pk) return launch_t<8, 8, HH, false, 512>(j, pl, io, s, dry)
   SADHIP_UH(9); SADHIP_UH(10); SADHIP_UH(11); SADHIP_UH(12); SADHIP_UH(13); SADHIP_UH(14); SADHIP_UH(15);   // BlockSize 18..31: two-lane halos
 #undef SADHIP_CASE
   return hipErrorInvalidValue;
+#endif
 }
 
+static bool passes_launchable(const Job& j, const std::vector<Pass>& passes)
+{
+  Job jj = j;
+  if (jj.n < 1) jj.n = 1;
+  if (jj.x1 <= jj.x0) { jj.x0 = 0; jj.x1 = jj.w; }
+  if (jj.y1 <= jj.y0) { jj.y0 = 0; jj.y1 = jj.h; }
+  for (const Pass& p : passes)
+    if (launch_pass(jj, p.pl, PassIo{p.dbase, nullptr, nullptr, jj.x1 - jj.x0}, nullptr, true) != hipSuccess) return false;
+  return true;
+}
+
+// No fallback in here: the generic kernel runs only when fast_supported() says so up front; any
+// launch error of a pass is returned to the caller (single-pass and multi-pass alike).
 hipError_t launch_fast(const Job& j, hipStream_t s)
 {
   if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
@@ -947,7 +1009,8 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
   const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2);
   if (passes.size() == 1) {
     const hipError_t e = launch_pass(j, passes[0].pl, PassIo{0, nullptr, nullptr, 0}, s);
-    return e == hipErrorInvalidValue ? launch_generic(j, s) : e;
+    if (e == hipSuccess) note_launch(KIND_COLWAVE);
+    return e;
   }
   // several passes: a u32 key per output pixel travels from pass to pass in a stream-ordered
   // scratch buffer (<= 256 MB: frames are processed in chunks)
@@ -971,6 +1034,7 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
     }
   }
   const hipError_t ef = hipFreeAsync(keys, s);
+  if (e == hipSuccess && ef == hipSuccess) note_launch(KIND_COLWAVE);
   return e != hipSuccess ? e : ef;
 }
 

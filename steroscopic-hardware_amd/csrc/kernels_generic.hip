@@ -12,6 +12,10 @@
 
 namespace sadhip {
 
+static thread_local int g_last_kind = KIND_NONE;
+void note_launch(int kind) { g_last_kind = kind; }
+int last_launch_kind() { return g_last_kind; }
+
 __global__ void __launch_bounds__(256)
 k_disparity_generic(Job j)
 {
@@ -54,6 +58,13 @@ k_disparity_generic(Job j)
 //           d in [0,D] is a candidate; window terms with xr < 0 are skipped (:83-85); strict '<'.
 //   mode 2  hardware/test.py:262-294  both images zero-padded by win/2, the padded right image
 //           shifted by d with zero fill, box sum of |L-R|, strict '<'; output for every pixel.
+//   mode 3  hardware/compute_SAD.v:62-265 (compute_max_disp): the OPPOSITE sign convention -- the
+//           right window slides to LARGER columns (col_index + disp_idx, :213); d runs over
+//           [0, MAX_DISP) EXCLUSIVE (:206-215); a candidate whose right window would leave the strip
+//           is not searched (the testbench strips are MAX_DISP columns wide, ez_tb.v); strict '<'
+//           (:201-204; the sad == 0 early stop is result-neutral); interior pixels only (the FSM
+//           needs a full WIN x WIN window), border 0.  A WIN-row strip gives its result at
+//           (x, y) = (col_index + WIN/2, WIN/2).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_disparity_mirror(Job j, int mode)
@@ -66,8 +77,22 @@ k_disparity_mirror(Job j, int mode)
   const uint8_t* __restrict__ R = j.right + (size_t)f * j.right_frame_stride;
   const int m = j.block / 2;
   int best = 0;
-  if (mode == 1 && (x < m || x >= j.w - m || y < m || y >= j.h - m)) {
+  if ((mode == 1 || mode == 3) && (x < m || x >= j.w - m || y < m || y >= j.h - m)) {
     best = 0;                                                   // sad.c:68-69: border stays 0
+  } else if (mode == 3) {
+    unsigned best_sad = 0xffffffffu;
+    for (int d = 0; d < j.maxdisp && x + m + d < j.w; ++d) {    // compute_SAD.v:206-215, window inside the strip
+      unsigned sad = 0;
+      for (int dy = -m; dy <= m; ++dy) {
+        const uint8_t* lp = L + (size_t)(y + dy - j.row0) * j.lstride + x;
+        const uint8_t* rp = R + (size_t)(y + dy - j.row0) * j.rstride + x + d;   // :213
+        for (int dx = -m; dx <= m; ++dx) {
+          const int a = lp[dx], b = rp[dx];
+          sad += (unsigned)(a >= b ? a - b : b - a);
+        }
+      }
+      if (sad < best_sad) { best_sad = sad; best = d; }         // :201-204
+    }
   } else {
     unsigned best_sad = 0xffffffffu;
     for (int d = 0; d <= j.maxdisp; ++d) {
@@ -100,7 +125,9 @@ hipError_t launch_mirror(const Job& j, int mode, hipStream_t s)
   if (rw <= 0 || rh <= 0 || j.n <= 0) return hipSuccess;
   dim3 grid((rw + 63) / 64, (rh + 3) / 4, j.n);
   hipLaunchKernelGGL(k_disparity_mirror, grid, dim3(256), 0, s, j, mode);
-  return hipGetLastError();
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) note_launch(mode == 1 ? KIND_MIRROR_SADC : mode == 2 ? KIND_MIRROR_TESTPY : KIND_MIRROR_VERILOG);
+  return e;
 }
 
 hipError_t launch_generic(const Job& j, hipStream_t s)
@@ -119,6 +146,7 @@ hipError_t launch_generic(const Job& j, hipStream_t s)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
+  note_launch(KIND_GENERIC);
   return hipSuccess;
 }
 

@@ -10,8 +10,12 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 using namespace sadhip;
 
@@ -92,11 +96,12 @@ struct sadhip_ctx {
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* h_scratch = nullptr; size_t h_scratch_bytes = 0;
   float last_kernel_ms = 0.f, last_total_ms = 0.f;
-  // Host copies.  Default: hipMemcpy2DAsync straight from / to the caller's (pageable) buffers --
-  // the runtime's own staging measured 2.2x faster than memcpy into pinned planes + linear copies
+  // Host copies: hipMemcpy2DAsync straight from / to the caller's (pageable) buffers -- the
+  // runtime's own staging measured 2.2x faster than memcpy into pinned planes + linear copies
   // (0.27 vs 0.58 ms per 1080p pair; 6 700 vs 2 900 pairs/s pipelined).  Every host entry point
-  // synchronises its stream before returning, so no caller pointer outlives the call either way.
-  // SADHIP_PINNED_STAGING=1 selects the pinned-plane path (kept for comparison).
+  // synchronises its stream before returning -- on error exits too -- so no caller pointer
+  // outlives the call.  The pinned-plane path survives only in the diagnostics build
+  // (-DSADHIP_TUNING, SADHIP_PINNED_STAGING=1) for comparison; the product reads no environment.
   bool pinned_staging = false;
   std::mutex mu;
 };
@@ -144,7 +149,7 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
   if (!out) return fail(SADHIP_ERR_NULL, "out is NULL");
   *out = nullptr;
   if (max_w <= 0 || max_h <= 0) return fail(SADHIP_ERR_DIMS, "max_w=%d max_h=%d", max_w, max_h);
-  if (max_batch < 1) return fail(SADHIP_ERR_BATCH, "max_batch=%d", max_batch);
+  if (max_batch < 1) return fail(SADHIP_ERR_BATCH, "max_batch=%d", max_batch);   // a hint only: batches of any length stream through two frame slots
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SADHIP_ERR_NO_DEVICE, "no HIP device");
   if (device < 0 || device >= n) return fail(SADHIP_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
@@ -155,7 +160,9 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
   c->device = device; c->max_w = max_w; c->max_h = max_h; c->max_batch = max_batch;
   c->pitch = align_up((size_t)max_w, 256);
   c->plane = c->pitch * (size_t)max_h;
+#ifdef SADHIP_TUNING
   c->pinned_staging = getenv("SADHIP_PINNED_STAGING") != nullptr;
+#endif
   for (auto& s : c->slot) {
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
@@ -207,10 +214,21 @@ static int check_params(int w, int h, int lstride, int rstride, int block, int m
   return SADHIP_OK;
 }
 
+static int check_flags(unsigned flags)
+{
+  const unsigned mirrors = SADHIP_FLAG_MIRROR_SADC | SADHIP_FLAG_MIRROR_TESTPY | SADHIP_FLAG_MIRROR_VERILOG;
+  const unsigned known = SADHIP_FLAG_RAW | SADHIP_FLAG_FORCE_GENERIC | mirrors;
+  if (flags & ~known) return fail(SADHIP_ERR_ARG, "unknown flag bits 0x%x", flags & ~known);
+  const unsigned m = flags & mirrors;
+  if (m & (m - 1)) return fail(SADHIP_ERR_ARG, "flags 0x%x select more than one hardware-mirror mode", flags);
+  return SADHIP_OK;
+}
+
 static hipError_t dispatch(const Job& j, unsigned flags, hipStream_t s)
 {
   if (flags & SADHIP_FLAG_MIRROR_SADC) return launch_mirror(j, 1, s);
   if (flags & SADHIP_FLAG_MIRROR_TESTPY) return launch_mirror(j, 2, s);
+  if (flags & SADHIP_FLAG_MIRROR_VERILOG) return launch_mirror(j, 3, s);
   if (!(flags & SADHIP_FLAG_FORCE_GENERIC) && fast_supported(j)) return launch_fast(j, s);
   return launch_generic(j, s);
 }
@@ -224,9 +242,14 @@ extern "C" int sadhip_plan_describe(int w, int h, int block, int maxdisp, char* 
   return describe_fast(j, buf, cap);
 }
 
+extern "C" int sadhip_last_kernel_kind(void) { return last_launch_kind(); }
+
 extern "C" int sadhip_kernel_kind(int w, int h, int block, int maxdisp, unsigned flags)
 {
-  if (check_params(w, h, w, w, block, maxdisp) != SADHIP_OK) return -1;
+  if (check_params(w, h, w, w, block, maxdisp) != SADHIP_OK || check_flags(flags) != SADHIP_OK) return -1;
+  if (flags & SADHIP_FLAG_MIRROR_SADC) return KIND_MIRROR_SADC;
+  if (flags & SADHIP_FLAG_MIRROR_TESTPY) return KIND_MIRROR_TESTPY;
+  if (flags & SADHIP_FLAG_MIRROR_VERILOG) return KIND_MIRROR_VERILOG;
   Job j{}; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp; j.n = 1;
   j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.lstride = j.rstride = j.ostride = w;
   if (flags & SADHIP_FLAG_FORCE_GENERIC) return 0;
@@ -308,6 +331,7 @@ extern "C" int sadhip_disparity_region_u8(sadhip_ctx* ctx, const uint8_t* left, 
 {
   if (!ctx || !left || !right || !out_region) return fail(SADHIP_ERR_NULL, "ctx/left/right/out is NULL");
   if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (int st = check_flags(flags)) return st;
   if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
   if (x0 < 0 || y0 < 0 || x1 > w || y1 > h || x0 >= x1 || y0 >= y1)
     return fail(SADHIP_ERR_REGION, "region (%d,%d)-(%d,%d) not inside %dx%d", x0, y0, x1, y1, w, h);
@@ -318,10 +342,10 @@ extern "C" int sadhip_disparity_region_u8(sadhip_ctx* ctx, const uint8_t* left, 
   const int band0 = y0 - hs < 0 ? 0 : y0 - hs;
   const int band1 = y1 + hs > h ? h : y1 + hs;
   Slot& s = ctx->slot[0];
-  if (int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags,
-                             x0, y0, x1, y1, band0, band1)) return st;
   float kms = 0.f;
-  if (int st = finish_frame(ctx, s, w, x0, y0, x1, y1, out_region, x1 - x0, &kms)) return st;
+  int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags, x0, y0, x1, y1, band0, band1);
+  if (st == SADHIP_OK) st = finish_frame(ctx, s, w, x0, y0, x1, y1, out_region, x1 - x0, &kms);
+  if (st != SADHIP_OK) { (void)hipStreamSynchronize(s.stream); return st; }   // no copy from/to caller memory left in flight
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
   return SADHIP_OK;
@@ -333,16 +357,17 @@ extern "C" int sadhip_disparity_u8(sadhip_ctx* ctx, const uint8_t* left, const u
 {
   if (!ctx || !left || !right || !out) return fail(SADHIP_ERR_NULL, "ctx/left/right/out is NULL");
   if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (int st = check_flags(flags)) return st;
   if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
   if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPTRY(hipSetDevice(ctx->device));
   const auto t0 = clk::now();
   Slot& s = ctx->slot[0];
-  if (int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags,
-                             0, 0, w, h, 0, h)) return st;
   float kms = 0.f;
-  if (int st = finish_frame(ctx, s, w, 0, 0, w, h, out, ostride, &kms)) return st;
+  int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags, 0, 0, w, h, 0, h);
+  if (st == SADHIP_OK) st = finish_frame(ctx, s, w, 0, 0, w, h, out, ostride, &kms);
+  if (st != SADHIP_OK) { (void)hipStreamSynchronize(s.stream); return st; }
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
   return SADHIP_OK;
@@ -361,6 +386,7 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
   for (int i = 0; i < n; ++i)
     if (!lefts[i] || !rights[i] || !outs[i]) return fail(SADHIP_ERR_NULL, "frame %d has a NULL pointer", i);
   if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (int st = check_flags(flags)) return st;
   if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
   if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -369,7 +395,11 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
   float kms = 0.f;
   // two-slot software pipeline: while slot A's frame is on the GPU, the host stages and
   // enqueues the next frame on slot B, then drains A.
+#ifdef SADHIP_TUNING
   static const bool seq = getenv("SADHIP_BATCH_SEQ") != nullptr;      // tuning aid: no cross-frame overlap
+#else
+  constexpr bool seq = false;
+#endif
   if (seq) {
     for (int i = 0; i < n; ++i) {
       if (int st = enqueue_frame(ctx, ctx->slot[0], lefts[i], rights[i], w, h, lstride, rstride, block, maxdisp, flags, 0, 0, w, h, 0, h)) return st;
@@ -414,6 +444,7 @@ extern "C" int sadhip_disparity_dev_u8(sadhip_ctx* ctx, int n,
   if (n == 0) return SADHIP_OK;
   if (!d_left || !d_right || !d_out) return fail(SADHIP_ERR_NULL, "d_left/d_right/d_out is NULL");
   if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (int st = check_flags(flags)) return st;
   if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
   if (n > 1) {
     const size_t need_l = (size_t)(h - 1) * lstride + w, need_r = (size_t)(h - 1) * rstride + w,
@@ -435,6 +466,17 @@ extern "C" int sadhip_disparity_dev_u8(sadhip_ctx* ctx, int n,
   hipStream_t s = (hipStream_t)hip_stream;   // NULL = HIP's null stream (torch's default stream)
   HIPTRY(dispatch(j, flags, s));
   return SADHIP_OK;
+}
+
+// Runs body(); on any failure waits for the stream, so that no asynchronous copy from / to the
+// caller's buffers is still in flight when the entry point returns (header: host pointers are
+// never retained after return -- the cgo rule).
+template <class F>
+static int synced_on_error(hipStream_t s, F&& body)
+{
+  const int st = body();
+  if (st != SADHIP_OK && s) (void)hipStreamSynchronize(s);
+  return st;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -471,13 +513,15 @@ extern "C" int sadhip_sad_windows_u8(sadhip_ctx* ctx,
   for (int r = 0; r < rh; ++r) memcpy(hs + off_r + (size_t)r * rw, right + (size_t)r * rstride, (size_t)rw);
   memcpy(hs + off_q, queries, qbytes);
   hipStream_t s = ctx->slot[0].stream;
-  HIPTRY(hipMemcpyAsync(ds, hs, off_o, hipMemcpyHostToDevice, s));
-  HIPTRY(launch_sad_windows(ds, lw, lh, lw, ds + off_r, rw, rh, rw, block, n,
-                            (const int32_t*)(ds + off_q), (int32_t*)(ds + off_o), s));
-  HIPTRY(hipMemcpyAsync(hs + off_o, ds + off_o, obytes, hipMemcpyDeviceToHost, s));
-  HIPTRY(hipStreamSynchronize(s));
-  memcpy(out_sad, hs + off_o, obytes);
-  return SADHIP_OK;
+  return synced_on_error(s, [&]() -> int {
+    HIPTRY(hipMemcpyAsync(ds, hs, off_o, hipMemcpyHostToDevice, s));
+    HIPTRY(launch_sad_windows(ds, lw, lh, lw, ds + off_r, rw, rh, rw, block, n,
+                              (const int32_t*)(ds + off_q), (int32_t*)(ds + off_o), s));
+    HIPTRY(hipMemcpyAsync(hs + off_o, ds + off_o, obytes, hipMemcpyDeviceToHost, s));
+    HIPTRY(hipStreamSynchronize(s));
+    memcpy(out_sad, hs + off_o, obytes);
+    return SADHIP_OK;
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -503,18 +547,22 @@ extern "C" int sadhip_gray_u8(sadhip_ctx* ctx, const uint8_t* pix, int channels,
   const size_t prow = align_up((size_t)w * channels, 16), pbytes = prow * h;
   const size_t grow = align_up((size_t)w, 16), gbytes = grow * h;
   const size_t off_g = align_up(pbytes, 256);
-  if (int st = ensure_scratch(ctx, off_g + gbytes, off_g + gbytes)) return st;
-  uint8_t* hs = (uint8_t*)ctx->h_scratch; uint8_t* ds = (uint8_t*)ctx->d_scratch;
-  for (int r = 0; r < h; ++r) memcpy(hs + (size_t)r * prow, pix + (size_t)r * stride, (size_t)w * channels);
+  if (int st = ensure_scratch(ctx, off_g + gbytes, 0)) return st;
+  uint8_t* ds = (uint8_t*)ctx->d_scratch;
   hipStream_t s = ctx->slot[0].stream;
-  HIPTRY(hipMemcpyAsync(ds, hs, pbytes, hipMemcpyHostToDevice, s));
-  HIPTRY(launch_gray(ds, channels, w, h, (int)prow, ds + off_g, (int)grow, s));
-  HIPTRY(hipMemcpyAsync(hs + off_g, ds + off_g, gbytes, hipMemcpyDeviceToHost, s));
-  HIPTRY(hipStreamSynchronize(s));
-  for (int r = 0; r < h; ++r) memcpy(gray + (size_t)r * gstride, hs + off_g + (size_t)r * grow, (size_t)w);
-  return SADHIP_OK;
+  return synced_on_error(s, [&]() -> int {
+    // one 2-D copy per direction straight from / to the caller's rows (no host staging copy)
+    HIPTRY(hipMemcpy2DAsync(ds, prow, pix, (size_t)stride, (size_t)w * channels, h, hipMemcpyHostToDevice, s));
+    HIPTRY(launch_gray(ds, channels, w, h, (int)prow, ds + off_g, (int)grow, s));
+    HIPTRY(hipMemcpy2DAsync(gray, (size_t)gstride, ds + off_g, grow, (size_t)w, h, hipMemcpyDeviceToHost, s));
+    HIPTRY(hipStreamSynchronize(s));
+    return SADHIP_OK;
+  });
 }
 
+// RGBA/RGB pair in, disparity out.  One upload per image (2-D copy from the caller's rows into
+// device scratch), gray conversion into the slot's device planes, disparity kernel, one download:
+// no host gray plane and no second H2D.
 extern "C" int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
                                         const uint8_t* left_pix, const uint8_t* right_pix, int channels,
                                         int w, int h, int lstride, int rstride,
@@ -525,36 +573,37 @@ extern "C" int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
   if (int st = check_pix(left_pix, channels, w, h, lstride)) return st;
   if (int st = check_pix(right_pix, channels, w, h, rstride)) return st;
   if (int st = check_params(w, h, w, w, block, maxdisp)) return st;
+  if (int st = check_flags(flags)) return st;
   if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
   if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPTRY(hipSetDevice(ctx->device));
   const auto t0 = clk::now();
   const size_t prow = align_up((size_t)w * channels, 16), pbytes = align_up(prow * h, 256);
-  if (int st = ensure_scratch(ctx, 2 * pbytes, 2 * pbytes)) return st;
-  uint8_t* hs = (uint8_t*)ctx->h_scratch; uint8_t* ds = (uint8_t*)ctx->d_scratch;
-  for (int r = 0; r < h; ++r) {
-    memcpy(hs + (size_t)r * prow, left_pix + (size_t)r * lstride, (size_t)w * channels);
-    memcpy(hs + pbytes + (size_t)r * prow, right_pix + (size_t)r * rstride, (size_t)w * channels);
-  }
+  if (int st = ensure_scratch(ctx, 2 * pbytes, 0)) return st;
+  uint8_t* ds = (uint8_t*)ctx->d_scratch;
   Slot& s = ctx->slot[0];
-  HIPTRY(hipMemcpyAsync(ds, hs, 2 * pbytes, hipMemcpyHostToDevice, s.stream));
-  HIPTRY(hipEventRecord(s.k0, s.stream));
-  const size_t gpitch = pitch_for(w);
-  HIPTRY(launch_gray(ds, channels, w, h, (int)prow, s.dL, (int)gpitch, s.stream));
-  HIPTRY(launch_gray(ds + pbytes, channels, w, h, (int)prow, s.dR, (int)gpitch, s.stream));
-  Job j{};
-  j.left = s.dL; j.right = s.dR; j.out = s.dO;
-  j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = ctx->plane;
-  j.lstride = j.rstride = j.ostride = (int)gpitch;
-  j.n = 1; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
-  j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.ox = 0; j.oy = 0;
-  j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
-  HIPTRY(dispatch(j, flags, s.stream));
-  HIPTRY(hipEventRecord(s.k1, s.stream));
-  if (ctx->pinned_staging) HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)h * gpitch, hipMemcpyDeviceToHost, s.stream));
   float kms = 0.f;
-  if (int st = finish_frame(ctx, s, w, 0, 0, w, h, out, ostride, &kms)) return st;
+  const int st = synced_on_error(s.stream, [&]() -> int {
+    HIPTRY(hipMemcpy2DAsync(ds, prow, left_pix, (size_t)lstride, (size_t)w * channels, h, hipMemcpyHostToDevice, s.stream));
+    HIPTRY(hipMemcpy2DAsync(ds + pbytes, prow, right_pix, (size_t)rstride, (size_t)w * channels, h, hipMemcpyHostToDevice, s.stream));
+    HIPTRY(hipEventRecord(s.k0, s.stream));
+    const size_t gpitch = pitch_for(w);
+    HIPTRY(launch_gray(ds, channels, w, h, (int)prow, s.dL, (int)gpitch, s.stream));
+    HIPTRY(launch_gray(ds + pbytes, channels, w, h, (int)prow, s.dR, (int)gpitch, s.stream));
+    Job j{};
+    j.left = s.dL; j.right = s.dR; j.out = s.dO;
+    j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = ctx->plane;
+    j.lstride = j.rstride = j.ostride = (int)gpitch;
+    j.n = 1; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
+    j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.ox = 0; j.oy = 0;
+    j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
+    HIPTRY(dispatch(j, flags, s.stream));
+    HIPTRY(hipEventRecord(s.k1, s.stream));
+    if (ctx->pinned_staging) HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)h * gpitch, hipMemcpyDeviceToHost, s.stream));
+    return finish_frame(ctx, s, w, 0, 0, w, h, out, ostride, &kms);
+  });
+  if (st != SADHIP_OK) return st;
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
   return SADHIP_OK;
@@ -566,5 +615,183 @@ extern "C" int sadhip_last_timing(sadhip_ctx* ctx, float* kernel_ms, float* tota
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (kernel_ms) *kernel_ms = ctx->last_kernel_ms;
   if (total_ms) *total_ms = ctx->last_total_ms;
+  return SADHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-device pool: one context and one host thread per entry of
+// devices[]; frame i of a batch goes to entry i mod G (the split north_star names); parameters
+// are fanned out by the host; results land in the caller's buffers.  No device-to-device
+// exchange exists on this path, so no collective is involved.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct PoolTask {
+  int n = 0;
+  const uint8_t* const* lefts = nullptr; const uint8_t* const* rights = nullptr; uint8_t* const* outs = nullptr;
+  int w = 0, h = 0, lstride = 0, rstride = 0, block = 0, maxdisp = 0, ostride = 0;
+  unsigned flags = 0;
+};
+
+struct PoolWorker {
+  sadhip_ctx* ctx = nullptr;
+  int index = 0, stride = 1;           // this worker's frames: index, index + stride, ...
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  const PoolTask* task = nullptr;      // posted by the caller, cleared by the worker
+  bool quit = false, done = false;
+  int status = SADHIP_OK;
+  int frames = 0;
+  float kernel_ms = 0.f;
+  char err[512] = "";
+};
+
+void pool_worker_main(PoolWorker* me)
+{
+  std::vector<const uint8_t*> L, R;
+  std::vector<uint8_t*> O;
+  for (;;) {
+    std::unique_lock<std::mutex> lk(me->mu);
+    me->cv.wait(lk, [&] { return me->task != nullptr || me->quit; });
+    if (me->quit) return;
+    const PoolTask* t = me->task;
+    lk.unlock();
+    int st = SADHIP_OK;
+    float kms = 0.f;
+    int frames = 0;
+    try {
+      L.clear(); R.clear(); O.clear();
+      for (int i = me->index; i < t->n; i += me->stride) { L.push_back(t->lefts[i]); R.push_back(t->rights[i]); O.push_back(t->outs[i]); }
+      frames = (int)L.size();
+      if (frames > 0) {
+        st = sadhip_disparity_batch_u8(me->ctx, frames, L.data(), R.data(), t->w, t->h, t->lstride, t->rstride,
+                                       t->block, t->maxdisp, t->flags, O.data(), t->ostride);
+        if (st == SADHIP_OK) (void)sadhip_last_timing(me->ctx, &kms, nullptr);
+      }
+    } catch (const std::bad_alloc&) {
+      st = fail(SADHIP_ERR_NOMEM, "pool worker %d: out of host memory", me->index);
+    } catch (...) {
+      st = fail(SADHIP_ERR_ARG, "pool worker %d: unexpected exception", me->index);
+    }
+    lk.lock();
+    me->status = st;
+    me->frames = frames;
+    me->kernel_ms = kms;
+    if (st != SADHIP_OK) snprintf(me->err, sizeof(me->err), "device entry %d: %s", me->index, g_err);   // g_err of THIS thread
+    me->task = nullptr;
+    me->done = true;
+    lk.unlock();
+    me->cv.notify_all();
+  }
+}
+
+}  // namespace
+
+struct sadhip_pool {
+  std::vector<std::unique_ptr<PoolWorker>> w;
+  std::mutex call_mu;                  // one batch at a time per pool
+  float last_wall_ms = 0.f, last_kernel_ms = 0.f;
+};
+
+static void destroy_pool(sadhip_pool* p)
+{
+  if (!p) return;
+  for (auto& w : p->w) {
+    if (w->th.joinable()) {
+      { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
+      w->cv.notify_all();
+      w->th.join();
+    }
+    if (w->ctx) destroy_ctx(w->ctx);
+  }
+  delete p;
+}
+
+extern "C" int sadhip_pool_create(const int* devices, int n_devices, int max_w, int max_h, sadhip_pool** out)
+{
+  if (!out) return fail(SADHIP_ERR_NULL, "out is NULL");
+  *out = nullptr;
+  if (!devices) return fail(SADHIP_ERR_NULL, "devices is NULL");
+  if (n_devices < 1 || n_devices > 64) return fail(SADHIP_ERR_ARG, "n_devices=%d (valid 1..64)", n_devices);
+  sadhip_pool* p = nullptr;
+  try {
+    p = new sadhip_pool();
+    for (int g = 0; g < n_devices; ++g) {
+      std::unique_ptr<PoolWorker> w(new PoolWorker());
+      w->index = g; w->stride = n_devices;
+      const int st = sadhip_ctx_create(devices[g], max_w, max_h, 1, &w->ctx);
+      if (st != SADHIP_OK) { destroy_pool(p); return st; }     // detail already in g_err
+      p->w.push_back(std::move(w));
+    }
+    for (auto& w : p->w) w->th = std::thread(pool_worker_main, w.get());
+  } catch (const std::bad_alloc&) {
+    destroy_pool(p);
+    return fail(SADHIP_ERR_NOMEM, "pool allocation failed");
+  } catch (const std::exception& e) {                          // std::system_error from std::thread
+    destroy_pool(p);
+    return fail(SADHIP_ERR_ARG, "pool threads: %s", e.what());
+  }
+  *out = p;
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_pool_destroy(sadhip_pool* pool)
+{
+  if (!pool) return fail(SADHIP_ERR_NULL, "pool is NULL");
+  destroy_pool(pool);
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_pool_size(const sadhip_pool* pool, int* n_devices)
+{
+  if (!pool || !n_devices) return fail(SADHIP_ERR_NULL, "pool or n_devices is NULL");
+  *n_devices = (int)pool->w.size();
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_pool_batch_u8(sadhip_pool* pool, int n,
+                                    const uint8_t* const* lefts, const uint8_t* const* rights,
+                                    int w, int h, int lstride, int rstride,
+                                    int block, int maxdisp, unsigned flags,
+                                    uint8_t* const* outs, int ostride)
+{
+  if (!pool) return fail(SADHIP_ERR_NULL, "pool is NULL");
+  if (n < 0) return fail(SADHIP_ERR_BATCH, "n=%d", n);
+  if (n == 0) return SADHIP_OK;
+  if (!lefts || !rights || !outs) return fail(SADHIP_ERR_NULL, "lefts/rights/outs is NULL");
+  for (int i = 0; i < n; ++i)
+    if (!lefts[i] || !rights[i] || !outs[i]) return fail(SADHIP_ERR_NULL, "frame %d has a NULL pointer", i);
+  if (int st = check_params(w, h, lstride, rstride, block, maxdisp)) return st;
+  if (int st = check_flags(flags)) return st;
+  if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
+  std::lock_guard<std::mutex> call(pool->call_mu);
+  const auto t0 = clk::now();
+  PoolTask t;
+  t.n = n; t.lefts = lefts; t.rights = rights; t.outs = outs;
+  t.w = w; t.h = h; t.lstride = lstride; t.rstride = rstride; t.block = block; t.maxdisp = maxdisp; t.ostride = ostride; t.flags = flags;
+  for (auto& wk : pool->w) {                                   // fan out: same parameters to every device
+    { std::lock_guard<std::mutex> lk(wk->mu); wk->done = false; wk->task = &t; }
+    wk->cv.notify_all();
+  }
+  int status = SADHIP_OK;
+  float kms = 0.f;
+  for (auto& wk : pool->w) {                                   // every worker finishes before t goes out of scope
+    std::unique_lock<std::mutex> lk(wk->mu);
+    wk->cv.wait(lk, [&] { return wk->done; });
+    if (wk->status != SADHIP_OK && status == SADHIP_OK) status = fail(wk->status, "%s", wk->err);
+    kms += wk->kernel_ms;
+  }
+  pool->last_kernel_ms = kms;
+  pool->last_wall_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+  return status;
+}
+
+extern "C" int sadhip_pool_last_timing(sadhip_pool* pool, float* kernel_ms_sum, float* wall_ms)
+{
+  if (!pool) return fail(SADHIP_ERR_NULL, "pool is NULL");
+  std::lock_guard<std::mutex> call(pool->call_mu);
+  if (kernel_ms_sum) *kernel_ms_sum = pool->last_kernel_ms;
+  if (wall_ms) *wall_ms = pool->last_wall_ms;
   return SADHIP_OK;
 }

@@ -27,11 +27,18 @@ struct Job {
   int row0;
 };
 
+// Which kernel the calling thread launched last (every launch_* records it on success); the C ABI
+// reports it through sadhip_last_kernel_kind() so tests and the bench can assert which code ran.
+enum { KIND_NONE = -1, KIND_GENERIC = 0, KIND_COLWAVE = 1, KIND_MIRROR_SADC = 2, KIND_MIRROR_TESTPY = 3, KIND_MIRROR_VERILOG = 4 };
+void note_launch(int kind);
+int last_launch_kind();
+
 // Generic kernel: any block / maxdisp / size.  One thread per output pixel, closed-form
 // restatement of sad.go:55-94 with u32 accumulators.  Always available.
 hipError_t launch_generic(const Job& j, hipStream_t s);
 
-// Hardware-mirror golden models (mode 1: hardware/sad.c, mode 2: hardware/test.py); raw d output.
+// Hardware-mirror golden models (mode 1: hardware/sad.c, mode 2: hardware/test.py, mode 3: the strip
+// search of hardware/compute_SAD.v); raw d output.
 hipError_t launch_mirror(const Job& j, int mode, hipStream_t s);
 
 // Fast kernel (kernels_fast.hip): returns true if it supports the job's parameters.

@@ -11,8 +11,14 @@ Differences from the reference, all deliberate:
   * AssembleDisparityMap writes every chunk it receives (the reference drops the last one,
     sad.go:181-184);
   * MaxDisparity < 1 raises instead of panicking with a divide by zero (sad.go:92);
+  * a device error inside the worker is carried to the consumer: AssembleDisparityMap raises it
+    instead of returning a partly black map (the reference has no error path at all);
   * there is no CPU path here: without the HIP library / a GPU every call raises.
+The device is chosen once per process from the environment variable SADHIP_DEVICE (default 0;
+the reference has no configuration precedent, SURVEY section 5 "config").
 """
+import contextlib
+import os
 import queue
 import threading
 from dataclasses import dataclass
@@ -64,10 +70,12 @@ _CLOSED = object()
 
 
 class Chan:
-    """Minimal Go-channel stand-in: send / iterate / close."""
+    """Minimal Go-channel stand-in: send / iterate / close.  ``error`` is the pipeline's error slot:
+    the worker stores its exception there before closing the output channel."""
 
     def __init__(self, cap):
         self._q = queue.Queue(maxsize=cap)
+        self.error = None
 
     def send(self, v):
         self._q.put(v)
@@ -87,39 +95,59 @@ class Chan:
 _ctx_lock = threading.Lock()
 _ctx = None
 _ctx_cap = (0, 0)
+_DEVICE = int(os.environ.get("SADHIP_DEVICE", "0"))          # read once (SURVEY section 5 "config")
 
 
-def _context(w, h, device=0):
-    """Process-wide device context, grown on demand (the worker pool of sad.go:41-104)."""
+@contextlib.contextmanager
+def _context(w, h):
+    """Process-wide device context, grown on demand (the worker pool of sad.go:41-104).
+    The lock is held for the WHOLE call that uses the context: a concurrent caller with a larger
+    frame can then never destroy it while another thread is inside sadhip_* with the old handle
+    (OutputCamera and RunSad callers are concurrent in the reference: output.go:37, examples/run.go:30).
+    Calls on one context are serialised inside the library anyway."""
     global _ctx, _ctx_cap
     with _ctx_lock:
         if _ctx is None or w > _ctx_cap[0] or h > _ctx_cap[1]:
             if _ctx is not None:
                 _ctx.close()
+                _ctx = None
             _ctx_cap = (max(w, _ctx_cap[0], 1920), max(h, _ctx_cap[1], 1080))
-            _ctx = capi.Context(device, _ctx_cap[0], _ctx_cap[1], 1)
-        return _ctx
+            _ctx = capi.Context(_DEVICE, _ctx_cap[0], _ctx_cap[1], 1)
+        yield _ctx
 
 
 def SetupConcurrentSAD(numWorkers):
     """sad.go:29-113.  Returns (inputChan, outputChan).  One device worker replaces the
     goroutine pool; parameters are snapshotted per chunk (sad.go:51-53); closing the input
-    channel stops the worker, which then closes the output channel (sad.go:106-110)."""
+    channel stops the worker, which then closes the output channel (sad.go:106-110).
+    On a device error the worker records it in outputChan.error, closes the output channel and
+    keeps draining the input channel, so a feeder blocked in send() is released and
+    AssembleDisparityMap raises instead of returning a short map."""
     if numWorkers <= 0:
         numWorkers = 32
     inp, outp = Chan(numWorkers * 2), Chan(numWorkers * 2)
 
     def worker():
+        failed = False
         try:
             for chunk in inp:
+                if failed:
+                    continue                                   # drain: never leave the feeder blocked
                 with _default_params_mu:
                     p = Parameters(_default_params.BlockSize, _default_params.MaxDisparity)
                 h, w = chunk.Left.shape
-                data = _context(w, h).disparity_region(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity,
-                                                       chunk.Region)
+                try:
+                    with _context(w, h) as c:
+                        data = c.disparity_region(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity, chunk.Region)
+                except Exception as e:                          # noqa: BLE001 -- carried to the consumer
+                    outp.error = e
+                    failed = True
+                    outp.close()
+                    continue
                 outp.send(OutputChunk(DisparityData=data.reshape(-1), Region=chunk.Region))
         finally:
-            outp.close()
+            if not failed:
+                outp.close()
 
     threading.Thread(target=worker, daemon=True).start()
     return inp, outp
@@ -136,6 +164,9 @@ def AssembleDisparityMap(outputChan, dimensions, chunks):
         i += 1
         if i >= chunks:
             break
+    if i < chunks:                                             # the stream ended early: never a silent black band
+        raise outputChan.error if getattr(outputChan, "error", None) is not None else \
+            RuntimeError(f"AssembleDisparityMap: output channel closed after {i} of {chunks} chunks")
     return disparityMap
 
 
@@ -145,13 +176,15 @@ def RunSad(left, right, blockSize, maxDisparity):
     the tiling: every worker reads the full shared images, sad.go:69-77)."""
     SetDefaultParams(Parameters(BlockSize=blockSize, MaxDisparity=maxDisparity))
     h, w = left.shape
-    return _context(w, h).disparity(left, right, blockSize, maxDisparity)
+    with _context(w, h) as c:
+        return c.disparity(left, right, blockSize, maxDisparity)
 
 
 def SumAbsoluteDifferences(left, right, leftX, leftY, rightX, rightY, blockSize):
     """sad.go:205-244 (one query through the batched device entry point)."""
     h, w = left.shape
-    return int(_context(w, h).sad_windows(left, right, blockSize, [(leftX, leftY, rightX, rightY)])[0])
+    with _context(max(w, right.shape[1]), max(h, right.shape[0])) as c:
+        return int(c.sad_windows(left, right, blockSize, [(leftX, leftY, rightX, rightY)])[0])
 
 
 def LoadPNG(filename, refbug_rgba=False):
@@ -173,7 +206,8 @@ def LoadPNG(filename, refbug_rgba=False):
     else:
         raise ValueError(f"LoadPNG {filename}: unsupported PNG mode {im.mode}")
     h, w = pix.shape[:2]
-    return _context(w, h).gray(pix)
+    with _context(w, h) as c:
+        return c.gray(pix)
 
 
 def MustLoadPNG(filename):

@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
+#include <map>
+#include <shared_mutex>
 #include <thread>
 
 namespace despair {
@@ -18,52 +21,99 @@ void check(int st, const char* what)
   if (st != SADHIP_OK) throw Error(st, std::string(what) + ": " + sadhip_status_string(st) + " (" + sadhip_last_error() + ")");
 }
 
-// process-wide context per device, grown on demand
-struct Ctx {
-  std::mutex mu; sadhip_ctx* h = nullptr; int w = 0, hgt = 0, device = 0;
-  ~Ctx() { if (h) sadhip_ctx_destroy(h); }
-  sadhip_ctx* get(int dev, int width, int height) {
+// Process-wide contexts, one per device, grown on demand.  A caller HOLDS A SHARED LOCK on its
+// device's entry for the whole sadhip_* call (Lease); growing takes the exclusive lock, so a context
+// is never destroyed while any thread is inside the library with its handle -- OutputCamera and
+// RunSad callers are concurrent in the reference (pkg/camera/output.go:37, examples/run.go:30).
+// A pipeline on another device has its own entry: nothing is torn down on a device change.
+struct DeviceCtx {
+  std::shared_mutex mu;
+  sadhip_ctx* h = nullptr;
+  int w = 0, hgt = 0;
+  ~DeviceCtx() { if (h) sadhip_ctx_destroy(h); }
+};
+
+struct Registry {
+  std::mutex mu;
+  std::map<int, std::unique_ptr<DeviceCtx>> by_device;
+  DeviceCtx& entry(int dev) {
     std::lock_guard<std::mutex> lk(mu);
-    if (!h || dev != device || width > w || height > hgt) {
-      if (h) { sadhip_ctx_destroy(h); h = nullptr; }
-      const int nw = width > 1920 ? width : 1920, nh = height > 1080 ? height : 1080;
-      check(sadhip_ctx_create(dev, nw > w ? nw : w, nh > hgt ? nh : hgt, 1, &h), "sadhip_ctx_create");
-      w = nw > w ? nw : w; hgt = nh > hgt ? nh : hgt; device = dev;
-    }
-    return h;
+    auto& e = by_device[dev];
+    if (!e) e.reset(new DeviceCtx());
+    return *e;
   }
 };
-Ctx& ctx() { static Ctx c; return c; }
+Registry& registry() { static Registry r; return r; }
+
+class Lease {
+ public:
+  Lease(int dev, int width, int height) : e_(registry().entry(dev)), lk_(e_.mu, std::defer_lock)
+  {
+    for (;;) {
+      lk_.lock();
+      if (e_.h && width <= e_.w && height <= e_.hgt) return;           // shared lock stays held until ~Lease
+      lk_.unlock();
+      std::unique_lock<std::shared_mutex> grow(e_.mu);                 // waits for every in-flight call
+      if (e_.h && width <= e_.w && height <= e_.hgt) continue;         // someone else grew it meanwhile
+      if (e_.h) { sadhip_ctx_destroy(e_.h); e_.h = nullptr; }
+      const int nw = std::max({width, e_.w, 1920}), nh = std::max({height, e_.hgt, 1080});
+      check(sadhip_ctx_create(dev, nw, nh, 1, &e_.h), "sadhip_ctx_create");
+      e_.w = nw; e_.hgt = nh;
+    }
+  }
+  sadhip_ctx* get() const { return e_.h; }
+ private:
+  DeviceCtx& e_;
+  std::shared_lock<std::shared_mutex> lk_;
+};
+
+thread_local float t_kernel_ms = 0.f, t_total_ms = 0.f;
+void note_timing(sadhip_ctx* h) { (void)sadhip_last_timing(h, &t_kernel_ms, &t_total_ms); }
+
+int dev_or_default(int device) { return device >= 0 ? device : DefaultDevice(); }
 }  // namespace
+
+int DefaultDevice()
+{
+  static const int d = [] { const char* e = getenv("SADHIP_DEVICE"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
+  return d;
+}
 
 void SetDefaultParams(Parameters p) { std::lock_guard<std::mutex> lk(g_params_mu); g_params = p; }
 Parameters DefaultParams() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
+void LastTiming(float* kernel_ms, float* total_ms) { if (kernel_ms) *kernel_ms = t_kernel_ms; if (total_ms) *total_ms = t_total_ms; }
 
 Pipeline SetupConcurrentSAD(int numWorkers, int device)
 {
   if (numWorkers <= 0) numWorkers = (int)std::thread::hardware_concurrency() * 4;      // sad.go:32-34
+  device = dev_or_default(device);
   Pipeline p{std::make_shared<Chan<InputChunk>>((size_t)numWorkers * 2),               // sad.go:36-37
              std::make_shared<Chan<OutputChunk>>((size_t)numWorkers * 2)};
   std::thread([in = p.in, out = p.out, device] {
     InputChunk c;
+    bool failed = false;
     while (in->recv(c)) {                                                              // sad.go:47
+      if (failed) continue;                                                            // drain: a feeder blocked in send() must get out
       const Parameters prm = DefaultParams();                                          // sad.go:51-53 (per chunk)
       OutputChunk o;
       o.Region = c.Region;
-      o.DisparityData.assign((size_t)c.Region.Dx() * c.Region.Dy(), 0);                // sad.go:48-50
       try {
+        o.DisparityData.assign((size_t)c.Region.Dx() * c.Region.Dy(), 0);              // sad.go:48-50
         const Gray& L = *c.Left; const Gray& R = *c.Right;
-        check(sadhip_disparity_region_u8(ctx().get(device, L.Rect.Dx(), L.Rect.Dy()), L.Pix.data(), R.Pix.data(),
+        Lease ctx(device, L.Rect.Dx(), L.Rect.Dy());
+        check(sadhip_disparity_region_u8(ctx.get(), L.Pix.data(), R.Pix.data(),
                                          L.Rect.Dx(), L.Rect.Dy(), L.Stride, R.Stride, prm.BlockSize, prm.MaxDisparity, 0,
                                          c.Region.x0, c.Region.y0, c.Region.x1, c.Region.y1, o.DisparityData.data()),
               "sadhip_disparity_region_u8");
-      } catch (const Error&) {
-        out->close();                                                                   // surface the failure: consumer sees a short stream
-        return;
+      } catch (...) {
+        out->fail(std::current_exception());                                           // the consumer gets the error, not a short stream
+        failed = true;
+        continue;
       }
-      out->send(std::move(o));                                                          // sad.go:98-101
+      try { out->send(std::move(o)); }                                                 // sad.go:98-101
+      catch (const std::logic_error&) { failed = true; }                               // consumer closed the output: drain and leave
     }
-    out->close();                                                                       // sad.go:106-110
+    if (!failed) out->close();                                                         // sad.go:106-110
   }).detach();
   return p;
 }
@@ -81,6 +131,11 @@ Gray AssembleDisparityMap(Chan<OutputChunk>& out, Rectangle dimensions, int chun
             c.DisparityData[(size_t)y * w + x];                                         // sad.go:186-197
     ++i;                                                                                // every chunk is written (no sad.go:181-184 hole)
   }
+  if (i < chunks) {                                                                     // never a silently short map
+    if (std::exception_ptr e = out.error()) std::rethrow_exception(e);
+    throw Error(SADHIP_ERR_ARG, "AssembleDisparityMap: output channel closed after " + std::to_string(i) + " of " +
+                                std::to_string(chunks) + " chunks");
+  }
   return m;
 }
 
@@ -88,10 +143,12 @@ Gray RunSad(const Gray& left, const Gray& right, int blockSize, int maxDisparity
 {
   SetDefaultParams(Parameters{blockSize, maxDisparity});                                // sad.go:123-126
   Gray out(left.Rect);
-  check(sadhip_disparity_u8(ctx().get(device, left.Rect.Dx(), left.Rect.Dy()), left.Pix.data(), right.Pix.data(),
+  Lease ctx(dev_or_default(device), left.Rect.Dx(), left.Rect.Dy());
+  check(sadhip_disparity_u8(ctx.get(), left.Pix.data(), right.Pix.data(),
                             left.Rect.Dx(), left.Rect.Dy(), left.Stride, right.Stride, blockSize, maxDisparity, 0,
                             out.Pix.data(), out.Stride),
         "sadhip_disparity_u8");
+  note_timing(ctx.get());
   return out;
 }
 
@@ -99,21 +156,30 @@ int SumAbsoluteDifferences(const Gray& left, const Gray& right, int leftX, int l
 {
   const int32_t q[4] = {leftX, leftY, rightX, rightY};
   int32_t r = 0;
-  check(sadhip_sad_windows_u8(ctx().get(0, left.Rect.Dx(), left.Rect.Dy()), left.Pix.data(), left.Rect.Dx(), left.Rect.Dy(), left.Stride,
+  Lease ctx(DefaultDevice(), std::max(left.Rect.Dx(), right.Rect.Dx()), std::max(left.Rect.Dy(), right.Rect.Dy()));
+  check(sadhip_sad_windows_u8(ctx.get(), left.Pix.data(), left.Rect.Dx(), left.Rect.Dy(), left.Stride,
                               right.Pix.data(), right.Rect.Dx(), right.Rect.Dy(), right.Stride, blockSize, 1, q, &r),
         "sadhip_sad_windows_u8");
   return r;
 }
 
 // ---- png.go ------------------------------------------------------------------------------------
-Gray LoadPNG(const std::string& filename, LoadPNGOptions opt)
+Picture LoadPicture(const std::string& filename)
 {
   PngImage im;
   std::string err;
   if (!read_png(filename, im, &err)) throw Error(SADHIP_ERR_ARG, "LoadPNG " + filename + ": " + err);
+  Picture p;
+  p.w = im.w; p.h = im.h; p.channels = im.channels; p.kind = (int)im.kind; p.depth16 = im.depth16;
+  p.samples = std::move(im.samples);
+  return p;
+}
+
+Gray ToGray(const Picture& im, LoadPNGOptions opt)
+{
   Gray g(im.w, im.h);
   const size_t npx = (size_t)im.w * im.h;
-  switch (im.kind) {
+  switch ((GoImage)im.kind) {
     case GoImage::Gray:                                         // png.go:31-32 -> gray.go:15-17
       g.Pix = im.samples;
       break;
@@ -121,10 +187,12 @@ Gray LoadPNG(const std::string& filename, LoadPNGOptions opt)
       if (opt.refbug_rgba) { std::fill(g.Pix.begin(), g.Pix.end(), 0); break; }   // 8-bit channels >> 24: always 0
       [[fallthrough]];
     case GoImage::NRGBA:
-    case GoImage::Paletted:                                     // png.go:35-36 -> gray.go:43-58, on the device
-      check(sadhip_gray_u8(ctx().get(opt.device, im.w, im.h), im.samples.data(), im.channels, im.w, im.h,
+    case GoImage::Paletted: {                                   // png.go:35-36 -> gray.go:43-58, on the device
+      Lease ctx(dev_or_default(opt.device), im.w, im.h);
+      check(sadhip_gray_u8(ctx.get(), im.samples.data(), im.channels, im.w, im.h,
                            im.w * im.channels, g.Pix.data(), g.Stride), "sadhip_gray_u8");
       break;
+    }
     case GoImage::Gray16:                                       // color.Gray16.RGBA() = (y, y, y): formula keeps the high byte
       for (size_t i = 0; i < npx; ++i) {
         const uint32_t y = (uint32_t)im.samples[2 * i] << 8 | im.samples[2 * i + 1];
@@ -147,11 +215,70 @@ Gray LoadPNG(const std::string& filename, LoadPNGOptions opt)
   return g;
 }
 
+Gray LoadPNG(const std::string& filename, LoadPNGOptions opt) { return ToGray(LoadPicture(filename), opt); }
+
+Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDisparity, int device, int* uploads_out)
+{
+  if (left.w != right.w || left.h != right.h)
+    throw Error(SADHIP_ERR_DIMS, "RunSad: left and right pictures differ in size");
+  if (left.device_gray_ok() && right.device_gray_ok() && left.channels == right.channels) {
+    SetDefaultParams(Parameters{blockSize, maxDisparity});                              // sad.go:123-126
+    Gray out(left.w, left.h);
+    Lease ctx(dev_or_default(device), left.w, left.h);
+    check(sadhip_disparity_rgba_u8(ctx.get(), left.samples.data(), right.samples.data(), left.channels, left.w, left.h,
+                                   left.w * left.channels, right.w * right.channels, blockSize, maxDisparity, 0,
+                                   out.Pix.data(), out.Stride),
+          "sadhip_disparity_rgba_u8");
+    note_timing(ctx.get());
+    if (uploads_out) *uploads_out = 2;                                                  // one per image; gray never visits the host
+    return out;
+  }
+  LoadPNGOptions opt; opt.device = device;
+  int up = 2;                                                                           // the two gray planes of RunSad
+  if (left.device_gray_ok() || (GoImage)left.kind == GoImage::Paletted) ++up;
+  if (right.device_gray_ok() || (GoImage)right.kind == GoImage::Paletted) ++up;
+  if (uploads_out) *uploads_out = up;
+  return RunSad(ToGray(left, opt), ToGray(right, opt), blockSize, maxDisparity, device);
+}
+
 void SavePNG(const std::string& filename, const Gray& img)
 {
   std::string err;
   if (!write_png_gray8(filename, img.Pix.data(), img.Rect.Dx(), img.Rect.Dy(), img.Stride, &err))
     throw Error(SADHIP_ERR_ARG, "SavePNG " + filename + ": " + err);
+}
+
+// ---- several devices -----------------------------------------------------------------------------
+DevicePool::DevicePool(const std::vector<int>& devices, int max_w, int max_h)
+{
+  check(sadhip_pool_create(devices.data(), (int)devices.size(), max_w, max_h, &p_), "sadhip_pool_create");
+}
+DevicePool::~DevicePool() { if (p_) sadhip_pool_destroy(p_); }
+int DevicePool::size() const { int n = 0; check(sadhip_pool_size(p_, &n), "sadhip_pool_size"); return n; }
+
+std::vector<Gray> DevicePool::RunSadBatch(const std::vector<std::shared_ptr<const Gray>>& lefts,
+                                          const std::vector<std::shared_ptr<const Gray>>& rights, int blockSize, int maxDisparity)
+{
+  if (lefts.size() != rights.size()) throw Error(SADHIP_ERR_BATCH, "RunSadBatch: lefts/rights differ in length");
+  SetDefaultParams(Parameters{blockSize, maxDisparity});
+  std::vector<Gray> outs;
+  if (lefts.empty()) return outs;
+  const Rectangle r = lefts[0]->Rect;
+  const int ls = lefts[0]->Stride, rs = rights[0]->Stride;
+  std::vector<const uint8_t*> pl, pr;
+  std::vector<uint8_t*> po;
+  outs.reserve(lefts.size());
+  for (size_t i = 0; i < lefts.size(); ++i) {
+    if (lefts[i]->Rect.Dx() != r.Dx() || lefts[i]->Rect.Dy() != r.Dy() || rights[i]->Rect.Dx() != r.Dx() || rights[i]->Rect.Dy() != r.Dy() ||
+        lefts[i]->Stride != ls || rights[i]->Stride != rs)
+      throw Error(SADHIP_ERR_DIMS, "RunSadBatch: frames of one batch must share size and stride");
+    outs.emplace_back(r);
+    pl.push_back(lefts[i]->Pix.data()); pr.push_back(rights[i]->Pix.data());
+  }
+  for (Gray& g : outs) po.push_back(g.Pix.data());
+  check(sadhip_pool_batch_u8(p_, (int)lefts.size(), pl.data(), pr.data(), r.Dx(), r.Dy(), ls, rs, blockSize, maxDisparity, 0,
+                             po.data(), r.Dx()), "sadhip_pool_batch_u8");
+  return outs;
 }
 
 }  // namespace despair

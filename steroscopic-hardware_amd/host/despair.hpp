@@ -13,20 +13,30 @@
 //   SumAbsoluteDifferences(...)                        despair::SumAbsoluteDifferences sad.go:205-244
 //   LoadPNG / MustLoadPNG / SavePNG / MustSavePNG      despair::LoadPNG/...           png.go:10-76
 //
+// Beyond the reference's surface:
+//   LoadPicture + RunSad(Picture, Picture)             decoded PNG samples stay in memory; an RGB(A) pair
+//                                                      is ONE sadhip_disparity_rgba_u8 call (one upload per
+//                                                      image, gray on the device, no host gray plane)
+//   DevicePool                                         sadhip_pool_*: frames round-robin over several devices
+//
 // Deliberate differences: AssembleDisparityMap writes every chunk (the
 // reference drops the last one, sad.go:181-184); errors are exceptions carrying the C-ABI status
-// instead of panics; there is no CPU fallback; LoadPNG of an opaque 8-bit RGB file returns its
-// luminance (the reference returns all zeros there, gray.go:20-40 -- LoadPNGOptions::refbug_rgba
-// reproduces that).
+// instead of panics -- a device error inside the pipeline worker reaches the consumer
+// (AssembleDisparityMap throws it; never a silently short, partly black map); there is no CPU
+// fallback; LoadPNG of an opaque 8-bit RGB file returns its luminance (the reference returns all
+// zeros there, gray.go:20-40 -- LoadPNGOptions::refbug_rgba reproduces that).
 #pragma once
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+struct sadhip_pool;
 
 namespace despair {
 
@@ -53,7 +63,9 @@ class Error : public std::runtime_error {
   int status;
 };
 
-// Buffered channel with Go semantics: send blocks when full, recv returns false once closed and drained.
+// Buffered channel with Go semantics: send blocks when full, recv returns false once closed and
+// drained.  fail() is the pipeline's error slot: it closes the channel and keeps the exception for
+// the consumer (error()).
 template <typename T>
 class Chan {
  public:
@@ -75,23 +87,33 @@ class Chan {
     return true;
   }
   void close() { std::lock_guard<std::mutex> lk(mu_); closed_ = true; cv_recv_.notify_all(); cv_send_.notify_all(); }
+  void fail(std::exception_ptr e) { std::lock_guard<std::mutex> lk(mu_); err_ = e; closed_ = true; cv_recv_.notify_all(); cv_send_.notify_all(); }
+  std::exception_ptr error() { std::lock_guard<std::mutex> lk(mu_); return err_; }
  private:
   std::mutex mu_; std::condition_variable cv_send_, cv_recv_; std::deque<T> q_; size_t cap_; bool closed_ = false;
+  std::exception_ptr err_;
 };
 
 struct Pipeline { std::shared_ptr<Chan<InputChunk>> in; std::shared_ptr<Chan<OutputChunk>> out; };
 
-// sad.go:29-113.  One device worker replaces the goroutine pool; closing `in` stops it and closes `out`.
-Pipeline SetupConcurrentSAD(int numWorkers, int device = 0);
-// sad.go:172-202 (hole-free).
+// Device used when a call does not name one: the environment variable SADHIP_DEVICE, read once
+// (default 0).  The reference has no configuration precedent (SURVEY section 5 "config").
+int DefaultDevice();
+
+// sad.go:29-113.  One device worker replaces the goroutine pool; closing `in` stops it and closes
+// `out`.  On a device error the worker fails `out` with the Error and keeps draining `in`, so a
+// feeder blocked in send() is released and the consumer sees the error.
+Pipeline SetupConcurrentSAD(int numWorkers, int device = -1);
+// sad.go:172-202 (hole-free).  Throws the pipeline's Error -- or Error(SADHIP_ERR_ARG) for a channel
+// closed early -- when fewer than `chunks` chunks arrive.
 Gray AssembleDisparityMap(Chan<OutputChunk>& out, Rectangle dimensions, int chunks);
 // sad.go:119-169: sets the global parameters, one frame-level device call.
-Gray RunSad(const Gray& left, const Gray& right, int blockSize, int maxDisparity, int device = 0);
+Gray RunSad(const Gray& left, const Gray& right, int blockSize, int maxDisparity, int device = -1);
 // png.go:10-41: decode, then the reference's type switch -- *image.Gray is copied, everything else
 // goes through the Go luminance formula on alpha-premultiplied 16-bit channels (gray.go:43-58),
 // computed on the device for 8-bit RGB/NRGBA (sadhip_gray_u8).  Throws Error(SADHIP_ERR_ARG, ..)
 // for unreadable files (LoadPNG returns (nil, err) in Go; MustLoadPNG panics).
-struct LoadPNGOptions { bool refbug_rgba = false; int device = 0; };
+struct LoadPNGOptions { bool refbug_rgba = false; int device = -1; };
 Gray LoadPNG(const std::string& filename, LoadPNGOptions opt = {});
 inline Gray MustLoadPNG(const std::string& filename) { return LoadPNG(filename); }
 // png.go:54-66: 8-bit gray PNG, fastest compression level.
@@ -100,5 +122,36 @@ inline void MustSavePNG(const std::string& filename, const Gray& img) { SavePNG(
 
 // sad.go:205-244.
 int SumAbsoluteDifferences(const Gray& left, const Gray& right, int leftX, int leftY, int rightX, int rightY, int blockSize);
+
+// ---- in-memory handoff: the decoded samples of a PNG, as png.Decode left them ----
+// kind/channels as in png_io.hpp (GoImage as int to keep that header out of this one).
+struct Picture {
+  int w = 0, h = 0, channels = 0, kind = 0; bool depth16 = false;
+  std::vector<uint8_t> samples;
+  bool device_gray_ok() const { return !depth16 && (channels == 3 || channels == 4); }   // 8-bit RGB / NRGBA
+};
+Picture LoadPicture(const std::string& filename);                   // decode only; nothing is converted or uploaded
+Gray ToGray(const Picture& p, LoadPNGOptions opt = {});             // the type switch of png.go:30-37 on a decoded picture
+// RunSad on decoded pictures.  Two 8-bit RGB(A) pictures of equal size and channel count: one
+// sadhip_disparity_rgba_u8 call (uploads: one per image; the gray planes exist only in HBM).
+// Anything else: ToGray + RunSad.  uploads_out (optional): number of host-to-device image uploads made.
+Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDisparity, int device = -1, int* uploads_out = nullptr);
+// device / wall time of the last RunSad of the calling thread ("elapsed" of output.go:200-204)
+void LastTiming(float* kernel_ms, float* total_ms);
+
+// ---- several devices: frame i of a batch runs on devices[i mod G] --------------------
+class DevicePool {
+ public:
+  DevicePool(const std::vector<int>& devices, int max_w, int max_h);
+  ~DevicePool();
+  DevicePool(const DevicePool&) = delete;
+  DevicePool& operator=(const DevicePool&) = delete;
+  int size() const;
+  // one map per pair; the global parameters are set like RunSad does (sad.go:123-126)
+  std::vector<Gray> RunSadBatch(const std::vector<std::shared_ptr<const Gray>>& lefts,
+                                const std::vector<std::shared_ptr<const Gray>>& rights, int blockSize, int maxDisparity);
+ private:
+  sadhip_pool* p_ = nullptr;
+};
 
 }  // namespace despair

@@ -1,23 +1,29 @@
 //go:build cgo && hip
 
-// Package despair -- MI355X backend.  Drop this file (and sad_nohip_tag.txt's build-tag edit)
-// into pkg/despair of conneroisu/steroscopic-hardware: it keeps every exported identifier of
-// sad.go (SetupConcurrentSAD, RunSad, AssembleDisparityMap, InputChunk, OutputChunk) and routes
-// the arithmetic to libsadhip.so through cgo.  Build with:
+// MI355X backend of pkg/despair.  New file, added next to sad.go after patches/0001 (which
+// gives the reference's Go entry points the unexported names setupConcurrentSADGo / runSadGo /
+// assembleDisparityMapGo; sad_cpu.go re-exports them for the default build).  This file exports
+// the same identifiers -- SetupConcurrentSAD, RunSad, AssembleDisparityMap -- and routes the
+// arithmetic to libsadhip.so (include/sadhip.h) through cgo.  Types (InputChunk, OutputChunk),
+// SumAbsoluteDifferences, Parameters and the PNG helpers stay where they are, shared by both builds.
 //
 //	CGO_ENABLED=1 go build -tags hip .
 //
-// and give the existing pure-Go sad.go the complementary constraint `//go:build !(cgo && hip)`
-// so release builds (CGO_ENABLED=0, .goreleaser.yaml:15-17) are unchanged.
+// Device: environment variable SADHIP_DEVICE (HIP ordinal, default 0), read once.
+// Fallback: any non-zero status logs a warning and runs the reference's own Go loop (the
+// unexported functions of sad.go) -- there is no second copy of that loop here.
 //
-// NOTE: this container has no Go toolchain (`go: command not found`), so this file is not
-// compiled by the repo's tests; the identical logic is exercised through the C++ mirror
-// (host/despair.cpp) and the ctypes mirror (despair.py), which call the same C ABI.
+// NOTE: the build container has no Go toolchain (`go: command not found`), so this file is not
+// compiled by the repository's tests; the identical logic is exercised through the C++ mirror
+// (host/despair.cpp, incl. a ThreadSanitizer run) and the ctypes mirror (despair.py).
 package despair
 
+// Header and library locations come from the environment, so the file works wherever the two
+// artefacts are installed:
+//	CGO_CFLAGS="-I<repo>/include" CGO_LDFLAGS="-L<repo>/steroscopic-hardware_amd/lib" go build -tags hip .
+
 /*
-#cgo CFLAGS:  -I${SRCDIR}/../../../include
-#cgo LDFLAGS: -L${SRCDIR}/../../lib -lsadhip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+#cgo LDFLAGS: -lsadhip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 #include <stdlib.h>
 #include "sadhip.h"
 */
@@ -27,83 +33,120 @@ import (
 	"fmt"
 	"image"
 	"log/slog"
+	"os"
 	"runtime"
+	"strconv"
 	"sync"
 	"unsafe"
 )
 
-// InputChunk represents a portion of the image to process (sad.go:11-15).
-type InputChunk struct {
-	Left, Right *image.Gray
-	Region      image.Rectangle
-}
+// FrameLevel: RunSad is one device call (see sad_cpu.go).
+const FrameLevel = true
 
-// OutputChunk represents the processed disparity data for a region (sad.go:17-21).
-type OutputChunk struct {
-	DisparityData []uint8
-	Region        image.Rectangle
-}
-
+// hipCtx is the process-wide device context, grown on demand.  Callers hold the READ lock for the
+// whole C call (with): growing takes the write lock, so a context is never destroyed while another
+// goroutine is inside libsadhip with its handle (OutputCamera and RunSad callers are concurrent:
+// pkg/camera/output.go:37, examples/run.go:30).
 type hipCtx struct {
-	mu   sync.Mutex
-	h    *C.sadhip_ctx
-	w, ht int
+	mu     sync.RWMutex
+	h      *C.sadhip_ctx
+	w, ht  int
+	device int
+	once   sync.Once
 }
 
 var ctx hipCtx
 
-// get returns a context able to hold w x h frames, growing it on demand.
-func (c *hipCtx) get(w, h int) (*C.sadhip_ctx, error) {
-	c.mu.Lock()
-	defer c.mu.Unlock()
-	if c.h == nil || w > c.w || h > c.ht {
-		if c.h != nil {
-			C.sadhip_ctx_destroy(c.h)
-			c.h = nil
+func (c *hipCtx) init() {
+	c.once.Do(func() {
+		if v, err := strconv.Atoi(os.Getenv("SADHIP_DEVICE")); err == nil && v >= 0 {
+			c.device = v
 		}
-		nw, nh := max(w, c.w, 1920), max(h, c.ht, 1080)
-		var out *C.sadhip_ctx
-		if st := C.sadhip_ctx_create(0, C.int(nw), C.int(nh), 1, &out); st != C.SADHIP_OK {
-			return nil, fmt.Errorf("sadhip_ctx_create: %s (%s)",
-				C.GoString(C.sadhip_status_string(st)), C.GoString(C.sadhip_last_error()))
-		}
-		c.h, c.w, c.ht = out, nw, nh
-	}
-	return c.h, nil
+	})
 }
 
+// statusErr must run on the OS thread that made the failing call: sadhip_last_error is thread-local.
 func statusErr(what string, st C.int) error {
 	return fmt.Errorf("%s: %s (%s)", what, C.GoString(C.sadhip_status_string(st)), C.GoString(C.sadhip_last_error()))
 }
 
-// regionHIP computes one chunk on the device.  Go pointers are only borrowed for the call
-// (libsadhip copies into pinned staging before returning), as cgo requires.
-func regionHIP(left, right *image.Gray, p Parameters, r image.Rectangle) ([]uint8, error) {
-	h, err := ctx.get(left.Rect.Dx(), left.Rect.Dy())
-	if err != nil {
-		return nil, err
+// with runs fn with a context able to hold w x h frames.  The goroutine is pinned to its OS thread
+// from the C call to the reading of the thread-local error detail.
+func (c *hipCtx) with(w, h int, fn func(*C.sadhip_ctx) error) error {
+	c.init()
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	for {
+		c.mu.RLock()
+		if c.h != nil && w <= c.w && h <= c.ht {
+			err := fn(c.h)
+			c.mu.RUnlock()
+			return err
+		}
+		c.mu.RUnlock()
+		c.mu.Lock() // waits for every call in flight
+		if c.h == nil || w > c.w || h > c.ht {
+			if c.h != nil {
+				C.sadhip_ctx_destroy(c.h)
+				c.h = nil
+			}
+			nw, nh := max(w, c.w, 1920), max(h, c.ht, 1080)
+			var out *C.sadhip_ctx
+			if st := C.sadhip_ctx_create(C.int(c.device), C.int(nw), C.int(nh), 1, &out); st != C.SADHIP_OK {
+				err := statusErr("sadhip_ctx_create", st)
+				c.mu.Unlock()
+				return err
+			}
+			c.h, c.w, c.ht = out, nw, nh
+		}
+		c.mu.Unlock()
 	}
+}
+
+// regionHIP computes one chunk on the device.  Go pointers are only borrowed for the call
+// (libsadhip copies from / to them with 2-D copies and waits for its stream before returning,
+// also on errors), as cgo requires.
+func regionHIP(left, right *image.Gray, p Parameters, r image.Rectangle) ([]uint8, error) {
 	data := make([]uint8, r.Dx()*r.Dy())
 	if len(data) == 0 {
 		return data, nil
 	}
-	st := C.sadhip_disparity_region_u8(h,
-		(*C.uint8_t)(unsafe.Pointer(&left.Pix[0])), (*C.uint8_t)(unsafe.Pointer(&right.Pix[0])),
-		C.int(left.Rect.Dx()), C.int(left.Rect.Dy()), C.int(left.Stride), C.int(right.Stride),
-		C.int(p.BlockSize), C.int(p.MaxDisparity), 0,
-		C.int(r.Min.X), C.int(r.Min.Y), C.int(r.Max.X), C.int(r.Max.Y),
-		(*C.uint8_t)(unsafe.Pointer(&data[0])))
-	runtime.KeepAlive(left)
-	runtime.KeepAlive(right)
-	if st != C.SADHIP_OK {
-		return nil, statusErr("sadhip_disparity_region_u8", st)
-	}
-	return data, nil
+	err := ctx.with(left.Rect.Dx(), left.Rect.Dy(), func(h *C.sadhip_ctx) error {
+		st := C.sadhip_disparity_region_u8(h,
+			(*C.uint8_t)(unsafe.Pointer(&left.Pix[0])), (*C.uint8_t)(unsafe.Pointer(&right.Pix[0])),
+			C.int(left.Rect.Dx()), C.int(left.Rect.Dy()), C.int(left.Stride), C.int(right.Stride),
+			C.int(p.BlockSize), C.int(p.MaxDisparity), 0,
+			C.int(r.Min.X), C.int(r.Min.Y), C.int(r.Max.X), C.int(r.Max.Y),
+			(*C.uint8_t)(unsafe.Pointer(&data[0])))
+		runtime.KeepAlive(left)
+		runtime.KeepAlive(right)
+		if st != C.SADHIP_OK {
+			return statusErr("sadhip_disparity_region_u8", st)
+		}
+		return nil
+	})
+	return data, err
 }
 
-// SetupConcurrentSAD sets up a concurrent SAD processing pipeline (sad.go:29-113).
-// One device worker replaces the goroutine pool; on any device error the chunk is computed by
-// the pure-Go worker body (cpuRegion, the unchanged loop of sad.go:55-94) so the WebUI keeps working.
+// goFallback is a lazily started instance of the reference's own worker pool (sad.go:29-113),
+// used for chunks the device refused.
+var goFallback struct {
+	once sync.Once
+	mu   sync.Mutex
+	in   chan<- InputChunk
+	out  <-chan OutputChunk
+}
+
+func regionGo(chunk InputChunk) OutputChunk {
+	goFallback.once.Do(func() { goFallback.in, goFallback.out = setupConcurrentSADGo(1) })
+	goFallback.mu.Lock() // one chunk in flight: the answer that comes back is this chunk's
+	defer goFallback.mu.Unlock()
+	goFallback.in <- chunk
+	return <-goFallback.out
+}
+
+// SetupConcurrentSAD sets up a concurrent SAD processing pipeline (sad.go:29-113): same channels,
+// same capacities, parameters snapshotted per chunk; one device worker replaces the goroutine pool.
 func SetupConcurrentSAD(numWorkers int) (chan<- InputChunk, <-chan OutputChunk) {
 	if numWorkers <= 0 {
 		numWorkers = runtime.NumCPU() * 4
@@ -113,13 +156,12 @@ func SetupConcurrentSAD(numWorkers int) (chan<- InputChunk, <-chan OutputChunk) 
 	go func() {
 		defer close(outputChan)
 		for chunk := range inputChan {
-			defaultParamsMu.Lock()
-			params := *defaultParams.Load() // per chunk, like sad.go:51-53
-			defaultParamsMu.Unlock()
+			params := *DefaultParams() // per chunk, like sad.go:51-53
 			data, err := regionHIP(chunk.Left, chunk.Right, params, chunk.Region)
 			if err != nil {
 				slog.Warn("HIP disparity failed, using the Go path", "err", err)
-				data = cpuRegion(chunk.Left, chunk.Right, params, chunk.Region)
+				outputChan <- regionGo(chunk)
+				continue
 			}
 			outputChan <- OutputChunk{DisparityData: data, Region: chunk.Region}
 		}
@@ -131,8 +173,10 @@ func SetupConcurrentSAD(numWorkers int) (chan<- InputChunk, <-chan OutputChunk) 
 func RunSad(left, right *image.Gray, blockSize, maxDisparity int) *image.Gray {
 	SetDefaultParams(Parameters{BlockSize: blockSize, MaxDisparity: maxDisparity})
 	out := image.NewGray(left.Rect)
-	h, err := ctx.get(left.Rect.Dx(), left.Rect.Dy())
-	if err == nil {
+	if len(out.Pix) == 0 {
+		return out
+	}
+	err := ctx.with(left.Rect.Dx(), left.Rect.Dy(), func(h *C.sadhip_ctx) error {
 		st := C.sadhip_disparity_u8(h,
 			(*C.uint8_t)(unsafe.Pointer(&left.Pix[0])), (*C.uint8_t)(unsafe.Pointer(&right.Pix[0])),
 			C.int(left.Rect.Dx()), C.int(left.Rect.Dy()), C.int(left.Stride), C.int(right.Stride),
@@ -140,14 +184,16 @@ func RunSad(left, right *image.Gray, blockSize, maxDisparity int) *image.Gray {
 			(*C.uint8_t)(unsafe.Pointer(&out.Pix[0])), C.int(out.Stride))
 		runtime.KeepAlive(left)
 		runtime.KeepAlive(right)
-		if st == C.SADHIP_OK {
-			return out
+		if st != C.SADHIP_OK {
+			return statusErr("sadhip_disparity_u8", st)
 		}
-		err = statusErr("sadhip_disparity_u8", st)
+		return nil
+	})
+	if err == nil {
+		return out
 	}
 	slog.Warn("HIP disparity failed, using the Go path", "err", err)
-	copy(out.Pix, cpuRegion(left, right, Parameters{blockSize, maxDisparity}, left.Rect))
-	return out
+	return runSadGo(left, right, blockSize, maxDisparity)
 }
 
 // AssembleDisparityMap assembles the disparity map from output chunks (sad.go:172-202).
@@ -168,33 +214,4 @@ func AssembleDisparityMap(outputChan <-chan OutputChunk, dimensions image.Rectan
 		}
 	}
 	return disparityMap
-}
-
-// cpuRegion is the reference worker body (sad.go:55-94) kept as the fallback path.
-func cpuRegion(left, right *image.Gray, params Parameters, region image.Rectangle) []uint8 {
-	data := make([]uint8, region.Dx()*region.Dy())
-	if params.MaxDisparity <= 0 {
-		return data // the reference panics here (divide by zero, sad.go:92)
-	}
-	for y := range region.Dy() {
-		globalY := region.Min.Y + y
-		for x := range region.Dx() {
-			minSAD := int(^uint(0) >> 1)
-			best := 0
-			for d := 0; d <= params.MaxDisparity; d++ {
-				if (region.Min.X+x)-d < left.Rect.Min.X {
-					continue
-				}
-				sad := SumAbsoluteDifferences(left, right, region.Min.X+x, globalY, region.Min.X+x-d, globalY, params.BlockSize)
-				if sad < minSAD {
-					minSAD, best = sad, d
-					if sad == 0 {
-						break
-					}
-				}
-			}
-			data[y*region.Dx()+x] = uint8((best * 255) / params.MaxDisparity)
-		}
-	}
-	return data
 }

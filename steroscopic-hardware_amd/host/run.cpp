@@ -1,7 +1,12 @@
 // run.cpp -- counterpart of the reference's examples/run.go: load the stereo pair, RunSad with the
 // default parameters of that example (16, 64), save the disparity map.
 //   usage: run [left.png right.png [out.png [block maxdisp]]]
+// The decoded pictures stay in memory between decode, disparity and SavePNG: an
+// RGB(A) pair is uploaded once per image and converted to gray on the device
+// (sadhip_disparity_rgba_u8) -- no host gray plane, no $HOME/*.png round trip.  The timing line
+// mirrors the "depth map generated" elapsed log of pkg/camera/output.go:200-204.
 #include "despair.hpp"
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -12,10 +17,21 @@ int main(int argc, char** argv)
   const char* out = argc > 3 ? argv[3] : "output.png";                  // run.go:31
   const int block = argc > 5 ? atoi(argv[4]) : 16, maxdisp = argc > 5 ? atoi(argv[5]) : 64;   // run.go:30
   try {
-    const despair::Gray L = despair::LoadPNG(left), R = despair::LoadPNG(right);
-    const despair::Gray got = despair::RunSad(L, R, block, maxdisp);
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    const despair::Picture L = despair::LoadPicture(left), R = despair::LoadPicture(right);
+    const auto t1 = clk::now();
+    int uploads = 0;
+    const despair::Gray got = despair::RunSad(L, R, block, maxdisp, -1, &uploads);
+    const auto t2 = clk::now();
+    float kernel_ms = 0.f, call_ms = 0.f;
+    despair::LastTiming(&kernel_ms, &call_ms);
     despair::SavePNG(out, got);
+    const auto t3 = clk::now();
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     printf("%s: %dx%d disparity map, block %d, max disparity %d\n", out, got.Rect.Dx(), got.Rect.Dy(), block, maxdisp);
+    printf("depth map generated elapsed=%.3fms decode=%.3fms disparity=%.3fms (device %.3fms, uploads %d) encode=%.3fms\n",
+           ms(t0, t3), ms(t0, t1), ms(t1, t2), kernel_ms, uploads, ms(t2, t3));
   } catch (const despair::Error& e) {
     fprintf(stderr, "despair error %d: %s\n", e.status, e.what());    // run.go panics
     return 1;

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     l = C.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(l, name), f"{name} not exported"
-    assert capi.lib().sadhip_abi_version() == 1
+    assert capi.lib().sadhip_abi_version() == capi.ABI_VERSION == 2
 
 
 def test_status_strings():
@@ -48,6 +48,53 @@ def test_kernel_kind_validates():
     assert capi.kernel_kind(10, 10, 0, 64) == -1
 
 
+def test_flags_are_validated_without_a_gpu():
+    """Unknown flag bits and two hardware-mirror modes at once are SADHIP_ERR_ARG, not a silent pick."""
+    M = capi
+    assert M.kernel_kind(128, 128, 15, 64, M.FLAG_MIRROR_SADC) == M.KIND_MIRROR_SADC
+    assert M.kernel_kind(128, 128, 15, 64, M.FLAG_MIRROR_TESTPY | M.FLAG_RAW) == M.KIND_MIRROR_TESTPY
+    assert M.kernel_kind(64, 15, 15, 64, M.FLAG_MIRROR_VERILOG) == M.KIND_MIRROR_VERILOG
+    assert M.kernel_kind(128, 128, 15, 64, M.FLAG_MIRROR_SADC | M.FLAG_MIRROR_TESTPY) == -1
+    assert M.kernel_kind(128, 128, 15, 64, M.FLAG_MIRROR_VERILOG | M.FLAG_MIRROR_TESTPY) == -1
+    assert M.kernel_kind(128, 128, 15, 64, 32) == -1 and M.kernel_kind(128, 128, 15, 64, 1 << 31) == -1
+    assert M.last_kernel_kind() == -1                           # nothing launched in this process yet (no GPU here)
+    l = M.lib()
+    h = C.c_void_p(1)                                           # flags are checked before the context is touched?  no: NULL checks first
+    assert l.sadhip_disparity_dev_u8(None, 1, None, None, 0, 0, 8, 8, 8, 8, 7, 32, 32, None, 0, 8, None) == M.ERR_NULL
+
+
+def test_product_library_reads_no_environment():
+    """The tuning knobs exist only in lib/libsadhip_tune.so (-DSADHIP_TUNING, tools/): the product
+    neither imports getenv nor carries a SADHIP_* variable name."""
+    import subprocess
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", capi.LIB_PATH], text=True)
+    assert "getenv" not in und
+    blob = open(capi.LIB_PATH, "rb").read()
+    for name in (b"SADHIP_TUNE", b"SADHIP_PINNED_STAGING", b"SADHIP_BATCH_SEQ", b"NOPEN"):
+        assert name not in blob, name
+
+
+def test_no_column_wave_kernel_spills():
+    """hipcc -Rpass-analysis=kernel-resource-usage over kernels_fast.hip (make remarks): every
+    instantiation launch_pass can reach must report 0 scratch, 0 VGPR spills and 0 SGPR spills."""
+    import subprocess
+    csrc = os.path.join(REPO, "steroscopic-hardware_amd", "csrc")
+    rem = os.path.join(REPO, "steroscopic-hardware_amd", "lib", "kernels_fast.remarks")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".inc"))]
+    if not os.path.exists(rem) or os.path.getmtime(rem) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", csrc, "remarks"], stdout=subprocess.DEVNULL)
+    blocks = re.split(r"remark: Function Name: ", open(rem).read())[1:]
+    assert len(blocks) >= 40
+    bad = []
+    for b in blocks:
+        name = b.split()[0]
+        val = lambda k: int(re.search(k + r": (\d+)", b).group(1))
+        sc, ss, vs = val(r"ScratchSize \[bytes/lane\]"), val("SGPRs Spill"), val("VGPRs Spill")
+        if sc or ss or vs:
+            bad.append((name, sc, ss, vs))
+    assert not bad, bad
+
+
 def test_null_and_bad_args_are_status_codes_not_crashes():
     l = capi.lib()
     assert l.sadhip_device_count(None) == capi.ERR_NULL
@@ -58,6 +105,13 @@ def test_null_and_bad_args_are_status_codes_not_crashes():
     assert l.sadhip_ctx_destroy(None) == capi.ERR_NULL
     assert l.sadhip_disparity_u8(None, None, None, 8, 8, 8, 8, 7, 32, 0, None, 8) == capi.ERR_NULL
     assert b"NULL" in l.sadhip_last_error()
+    p = C.c_void_p()
+    assert l.sadhip_pool_create(None, 1, 64, 64, C.byref(p)) == capi.ERR_NULL
+    dev = (C.c_int * 1)(0)
+    assert l.sadhip_pool_create(dev, 0, 64, 64, C.byref(p)) == capi.ERR_ARG
+    assert l.sadhip_pool_create(dev, 1, 64, 64, None) == capi.ERR_NULL
+    assert l.sadhip_pool_destroy(None) == capi.ERR_NULL
+    assert l.sadhip_pool_batch_u8(None, 0, None, None, 8, 8, 8, 8, 7, 32, 0, None, 8) == capi.ERR_NULL
 
 
 @pytest.mark.skipif(_has_gpu(), reason="this container-side test asserts the no-GPU behaviour")

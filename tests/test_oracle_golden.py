@@ -83,6 +83,21 @@ def test_verilog_strip_fixtures(hwfx):
     assert [int(v) for v in hwfx["exp_disp_old"]] == [0x23, 0x0E, 0x29, 0x31]
 
 
+def test_verilog_image_mirror_is_the_strip_search_at_every_pixel(hwfx):
+    """oracle.mirror_verilog (what the GPU's MIRROR_VERILOG mode is checked against) on a testbench
+    strip gives the fixture value at (x, y) = (WIN/2, WIN/2) = col_index 0, and equals the strip
+    function at every other col_index too."""
+    for L, R, exp in ((hwfx["strips_n_L"], hwfx["strips_n_R"], hwfx["exp_disp_n"]),
+                      (hwfx["strips_old_L"], hwfx["strips_old_R"], hwfx["exp_disp_old"])):
+        for k in range(4):
+            img = oracle.mirror_verilog(L[k], R[k], 15, 64)
+            assert int(img[7, 7]) == int(exp[k])
+            assert not img[:7].any() and not img[8:].any() and not img[:, :7].any() and not img[:, 57:].any()
+            for ci in (1, 5, 20, 49):                      # col_index ci: the strip starting at column ci
+                d, _ = oracle.mirror_verilog_strip(np.ascontiguousarray(L[k][:, ci:]), np.ascontiguousarray(R[k][:, ci:]), 15, 64)
+                assert int(img[7, 7 + ci]) == d
+
+
 def test_single_window_sad_kats(hwfx):
     """old_mems/exp_sad.mem = SAD of the first 15x15 window (d = 0) of each strip;
     winL/winR.mem -> 18116 (SAD_test.v:34-48).  Exercises SumAbsoluteDifferences (sad.go:205-244)."""

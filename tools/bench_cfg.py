@@ -6,7 +6,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "oracle")]
 import numpy as np, torch
 import steroscopic_hardware_amd as sha, oracle
-if os.environ.get("SADHIP_LIB"): sha.capi.LIB_PATH = os.path.abspath(os.environ["SADHIP_LIB"])   # tuning builds
+if os.environ.get("SADHIP_LIB"): sha.capi.LIB_PATH = os.path.abspath(os.environ["SADHIP_LIB"])   # other builds
+elif any(k.startswith("SADHIP_TUNE_") for k in os.environ):      # the knobs exist only in the diagnostics build (make -C csrc tune)
+    sha.capi.LIB_PATH = os.path.join(os.path.dirname(sha.capi.LIB_PATH), "libsadhip_tune.so")
 W, H, B, D = (int(v) for v in sys.argv[1:5]); N = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 dev = torch.device("cuda", 0)
 Ls, Rs = sha.synth.synth_batch_torch([1000 + i for i in range(N)], W, H, dev)
