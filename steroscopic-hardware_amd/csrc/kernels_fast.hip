@@ -65,7 +65,8 @@ struct CwArgs {
   int pixshift;    // left shift applied to pixels landing in LDS (unpacked: ksh; packed: 0)
   int dpad;        // columns of R kept left of the tile (== 3 mod 4, >= largest candidate)
   int tx0;         // origin of tile 0 (<= 0, == w mod P)
-  int tile0;       // first tile index launched (blockIdx.x + tile0)
+  int tile0;       // first tile index launched (blockIdx.y + tile0)
+  int nstrips;     // strips per frame: blockIdx.x = strip + nstrips * frame
   int th;          // output rows per strip
   int shl, shr;    // per-wave share of a ring row: L elements (= output pixels), R elements
   // Disparity ranges wider than one workgroup can hold run as several passes (launches) over
@@ -78,6 +79,16 @@ struct CwArgs {
 };
 
 constexpr unsigned KEY_INVALID = 0xffffffffu;
+#ifdef SADHIP_X_BUFLOAD
+constexpr bool X_BUFLOAD = true;
+#else
+constexpr bool X_BUFLOAD = false;
+#endif
+#ifdef SADHIP_X_NORECOMP
+constexpr bool X_NORECOMP = true;
+#else
+constexpr bool X_NORECOMP = false;
+#endif
 
 // |a - b| + acc in one instruction, in place.  Inline asm: left to itself hipcc canonicalises the
 // C++ form into v_max_u32 + v_min_u32 + v_sub/v_add3 (3 ops) inside the unrolled update.
@@ -186,16 +197,6 @@ __device__ __forceinline__ unsigned sel_lanes(unsigned long long mask, unsigned 
   asm("v_cndmask_b32 %0, -1, %1, %2" : "=v"(r) : "v"(key), "s"(mask));
   return r;
 }
-// lanes >= l0 keep the key (l0 >= 64: none).  The mask is built from l0 at the use (two scalar
-// instructions on the otherwise idle scalar unit): holding NM ready-made 64-bit masks cost 2*NM SGPRs
-// and spilled 13-15 of them in the packed h = 6, 7 variants.
-__device__ __forceinline__ unsigned sel_from(int l0, unsigned key)
-{
-  asm volatile("" : "+s"(l0));                          // keeps the mask from being hoisted out of the row loop again
-  const unsigned long long mask = l0 < 64 ? (~0ull << l0) : 0ull;
-  return sel_lanes(mask, key);
-}
-
 // Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also emits
 // s_waitcnt vmcnt(0): every wave would then sit at every row barrier until the output bytes it has
 // just stored are acknowledged (a full memory round trip per row).  Nothing depends on them;
@@ -372,7 +373,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // runs past MaxDisparity); the extra candidate's empty high half is dropped here (qn = 1).
   // JOFS = index of the array's first candidate within the wave (0; ND for the extra candidate).
   template <int MASK, int JOFS>
-  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const int (&M)[NM],
+  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const unsigned long long (&M)[NM],
                                                  unsigned (&best)[P], unsigned dbase, int qn)
   {
     // window sum of column p = own columns + last (h-p) columns of the left lane + first (p+h-P+1)
@@ -425,8 +426,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
         unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
         if (MASK == 2) {
           const int ie = JOFS + 2 * q - p + P - 1, io = ie + 1;
-          ke = sel_from(M[ie < NM ? ie : NM - 1], ke);
-          ko = (JOFS != 0 && 2 * q + 1 >= qn) ? KEY_INVALID : sel_from(M[io < NM ? io : NM - 1], ko);
+          ke = sel_lanes(M[ie < NM ? ie : NM - 1], ke);
+          ko = (JOFS != 0 && 2 * q + 1 >= qn) ? KEY_INVALID : sel_lanes(M[io < NM ? io : NM - 1], ko);
         }
         const unsigned m = ke < ko ? ke : ko;
         best[p] = m < best[p] ? m : best[p];                      // v_min3_u32
@@ -434,7 +435,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
         unsigned k = s[p];
         if (MASK == 2) {
           const int i = JOFS + q - p + P - 1;
-          k = sel_from(M[i < NM ? i : NM - 1], k);
+          k = sel_lanes(M[i < NM ? i : NM - 1], k);
         }
         best[p] = k < best[p] ? k : best[p];
       }
@@ -442,7 +443,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
   }
 
   template <int MASK, int JOFS, int W>
-  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const int (&M)[NM],
+  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const unsigned long long (&M)[NM],
                                                     unsigned (&best)[P], unsigned dbase, int qn)
   {
 #pragma unroll
@@ -471,14 +472,18 @@ struct Cw {                                         // P columns per lane: 4 (h 
     unsigned* rowbest = smem + (size_t)(NR + 1) * ROWW * sizeof(Px) / 4;   // [NB][RBW]  (ROWW * sizeof(Px) is a multiple of 16)
     unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + NB * RBW);  // [maxdisp+1]
 
-    const int tile = blockIdx.x + a.tile0;
+    // Grid = (strips x frames, tiles): workgroups are dispatched x-fastest, so ALL workgroups of the
+    // leftmost tile (the ones that mask keys in the packed h = 6, 7 variants and run longest) start in
+    // the first round instead of trailing the launch.
+    const int tile = blockIdx.y + a.tile0;
     const int tx = a.tx0 + tile * STEP;                   // image column of lane 0, p 0
-    const int f = blockIdx.z;
+    const int f = blockIdx.x / a.nstrips;
+    const int strip = blockIdx.x - f * a.nstrips;
     const uint8_t* __restrict__ Lg = j.left + (size_t)f * j.left_frame_stride;
     const uint8_t* __restrict__ Rg = j.right + (size_t)f * j.right_frame_stride;
     uint8_t* __restrict__ Og = j.out + (size_t)f * j.out_frame_stride;
 
-    const int ys = j.y0 + blockIdx.y * a.th;              // strip rows [ys, ye)
+    const int ys = j.y0 + strip * a.th;                   // strip rows [ys, ye)
     const int ye = min(ys + a.th, j.y1);
     // output columns of this tile (tile 0 also owns everything left of its interior)
     const int ox0 = max(tile == 0 ? j.x0 : tx + OL, j.x0);
@@ -532,13 +537,13 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // values are recomputed in every step from a lane id the compiler cannot see through (a dozen
     // VALU instructions per step) instead of being held -- held, they were spilled to scratch in the
     // set-up code and reloaded in every step (14-21 VGPRs, 60-88 bytes of scratch per lane).
-    constexpr bool RECOMPUTE_SHARE = !PK;
+    constexpr bool RECOMPUTE_SHARE = !PK && !X_NORECOMP;
     unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
     auto load_row = [&](int yy) {
       if (yy >= 0 && yy < j.h) {
         const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * j.lstride;
         const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * j.rstride;
-        if constexpr (PK) {
+        if constexpr (PK || X_BUFLOAD) {
           // one resource per row (scalar arithmetic): base = the row, num_records = its width
           const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lrow), 0, j.w, 0x00020000);
           const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(rrow), 0, j.w, 0x00020000);
@@ -618,12 +623,18 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // per value of j - p, kept in SGPRs and applied with one v_cndmask_b32 per key.
     constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
     constexpr bool use_pen = !NEED_MASK;
-    int M[NM];                                          // first lane whose key survives, per value of j - p (64: none)
+    // Lane masks, one 64-bit SGPR pair per value of j - p, held across the row loop.  They make these
+    // two kernel families (packed h = 6, 7) the only ones over the SGPR budget: the compiler parks
+    // 13-15 scalars in spare VGPR lanes (v_writelane / v_readlane; no scratch memory).  Measured
+    // alternatives: rebuilding each mask at its use from a one-SGPR lane
+    // threshold removes the spills and costs 8 % on config 5 (the leftmost tile's keys sit on the
+    // critical path); rebuilding all of them once per row step needs more SGPRs, not fewer.
+    unsigned long long M[NM];
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
       const int t = dc + H - tx + (k - (P - 1)) + P - 1;  // ceil(num / P) = floor((num + P-1) / P)
       const int l0 = t > 0 ? t / P : 0;
-      M[k] = (NEED_MASK && l0 < 64) ? l0 : 64;
+      M[k] = (NEED_MASK && l0 < 64) ? (~0ull << l0) : 0ull;
     }
     // Candidates d > D (a chunk that runs past MaxDisparity) exist for no pixel: same trick with the
     // class c == w-1 (mod 2h+1), 0 <= c < w, which every window has exactly once -- also the windows
@@ -914,7 +925,8 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
     const size_t koff = (size_t)f0 * (size_t)rows * (size_t)a.kw;      // the kernel indexes keys with its local frame number
     if (aa.kin) aa.kin += koff;
     if (aa.kout) aa.kout += koff;
-    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16>), dim3(ntiles, (unsigned)nstrips, aa.j.n), dim3(64 * pl.nw), lds, s, aa);
+    aa.nstrips = (int)nstrips;
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
