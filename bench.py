@@ -29,6 +29,36 @@ for _p in (REPO, os.path.join(REPO, "oracle")):
 
 W, H, BLOCK, MAXDISP = 1920, 1080, 9, 64
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS, CLOCK_GHZ = 256 * 4, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+VECTOR_PEAK_GWINST = SIMDS * CLOCK_GHZ / 2     # one wave-instruction per 2 cycles per SIMD (157.3 TF fp32 = this x 64 lanes x 2)
+
+
+def _source_digest():
+    """sha256 over the kernel sources: what profiles/*.json were measured on (tools/valu_budget.py)."""
+    import hashlib
+    csrc = os.path.join(REPO, "steroscopic-hardware_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _usable_cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def _time_reference_c(ctx, sha):
@@ -69,7 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-gpu", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU baseline (default: every core this process may use)")
     ap.add_argument("--flags", type=int, default=0, help="sadhip flags (2 = force generic kernel)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single GPU: every rank uses cuda:0 and the collectives run "
@@ -168,22 +198,48 @@ def main():
                      "note": "path is integer-VALU bound (SURVEY 8d); see gcand_per_s and DESIGN.md"},
     }
 
-    # HBM traffic per launch from the committed PMC profile (only when it is this exact launch shape)
+    ran = sha.capi.last_kernel_kind()                             # what the timed launches really ran (no silent fallback)
+    res["config"]["kernel_kind_ran"] = ran
+    if ran != res["config"]["kernel_kind"]:
+        res["parity_error"] = f"planned kernel kind {res['config']['kernel_kind']} but kind {ran} ran"
+
+    # Counter-derived figures come from the committed rocprofv3 profile of THIS launch shape and THESE
+    # kernel sources (profiles/traffic.json, profiles/valu_budget.json carry the digest of csrc/); a
+    # profile of other sources is reported as stale, never as current.
+    digest = _source_digest()
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        if (tj["frames_per_launch"], tj["width"], tj["height"], tj["block"], tj["maxdisp"]) == (F, W, H, block, maxdisp) \
-                and res["config"]["kernel_kind"] == 1:
-            res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-            res["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, round %d)" % tj["round"]
-            if "sq_insts_valu_per_launch" in tj:
-                # the binding resource: vector-ALU issue slots.  Wave-instructions per launch from the
-                # PMC profile (SQ_INSTS_VALU) over the launch time measured here, against one issue per
-                # 4 cycles per SIMD (256 CUs x 4 SIMDs at the 2.4 GHz peak clock, MI355X_MICROARCH.md).
-                ginst = tj["sq_insts_valu_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
-                peak = 256 * 4 * 2.4 / 4
-                res["roofline"]["valu"] = {"achieved": ginst, "peak": peak, "unit": "G wave-instructions/s", "frac": ginst / peak,
-                                           "insts_per_launch": tj["sq_insts_valu_per_launch"]}
+        same_shape = (tj["frames_per_launch"], tj["width"], tj["height"], tj["block"], tj["maxdisp"]) == (F, W, H, block, maxdisp)
+        if same_shape and res["config"]["kernel_kind"] == 1:
+            if tj.get("source_digest") == digest:
+                res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = tj.get("source", "profiles/traffic.json")
+            else:
+                res["roofline"]["traffic_source"] = "stale: profiles/traffic.json was measured on other kernel sources (digest %s, now %s)" % (tj.get("source_digest"), digest)
     except (OSError, KeyError, ValueError):
+        tj = None
+    try:
+        vb = json.load(open(os.path.join(REPO, "profiles", "valu_budget.json")))
+        cnt = vb["row_loop_common_path"]["counts"]
+        cost = vb["class_cost_cycles"]
+        issue = cnt["fast"] + cnt["slow"] + cnt["qrate"] + cnt["nop"]
+        cyc = sum(cnt[k] * cost[k] for k in cnt)
+        valu = {"unit": "G wave-instructions/s", "peak_vector_2cycle": VECTOR_PEAK_GWINST,
+                "mix_ceiling": SIMDS * CLOCK_GHZ / (cyc / issue),
+                "kernel": vb["kernel"], "class_counts_per_wave_step": cnt, "class_cost_cycles": cost,
+                "budget_source": "profiles/valu_budget.json (tools/valu_budget.py over the compiler's assembly)",
+                "note": "mix ceiling = issue rate if every instruction of the row loop cost exactly its class cost "
+                        "(fast 2, slow 4, s_nop 4 cycles per wave-instruction per SIMD, measured by tools/ubench/valu_rates*.hip)"}
+        if vb.get("source_digest") != digest:
+            valu["budget_source"] += " -- STALE (digest %s, sources now %s)" % (vb.get("source_digest"), digest)
+        if tj and tj.get("source_digest") == digest and "sq_insts_valu_per_launch" in tj and \
+                (tj["frames_per_launch"], tj["width"], tj["height"], tj["block"], tj["maxdisp"]) == (F, W, H, block, maxdisp):
+            ginst = tj["sq_insts_valu_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
+            valu.update({"achieved": ginst, "insts_per_launch": tj["sq_insts_valu_per_launch"],
+                         "frac_of_vector_peak": ginst / VECTOR_PEAK_GWINST, "frac_of_mix_ceiling": ginst / valu["mix_ceiling"],
+                         "insts_source": "SQ_INSTS_VALU of " + tj.get("source", "profiles/traffic.json")})
+        res["roofline"]["valu"] = valu
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
     if not args.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract)
@@ -194,19 +250,34 @@ def main():
         if ref_c:
             res["reference_c"] = ref_c
         import oracle
-        nthr = args.cpu_threads or min(16, os.cpu_count() or 1)
-        npairs = min(4, F)                                       # ~17 CPU-seconds of work at 16 threads
-        cpu_s, ok = 0.0, True
-        for i in range(npairs):
-            L0, R0 = Ls[i].cpu().numpy(), Rs[i].cpu().numpy()
-            t1 = time.perf_counter()
-            cpu = oracle.disparity_rows_mt(L0, R0, block, maxdisp, 0, H, nthr)  # one full pair
-            cpu_s += time.perf_counter() - t1
-            ok = ok and bool(np.array_equal(cpu, out[i].cpu().numpy()))
-        res["cpu_baseline"] = {"value": npairs / cpu_s, "unit": "pairs/s", "cores": nthr, "kind": "port",
-                               "sample": f"{npairs} full {W}x{H} pairs (frame seeds 1000..{1000 + npairs - 1} of this rank), literal "
-                                         f"restatement of pkg/despair sad.go:55-94 in C, {nthr} threads over output.go row bands, "
-                                         f"{cpu_s:.2f} s wall = {cpu_s * nthr:.0f} CPU-seconds", "gpu_output_matches": ok}
+        # CPU baseline: the literal C restatement of pkg/despair sad.go:55-94 on this box's
+        # host cores, same frames as the GPU: one thread, then every core this process may use (row bands
+        # like output.go:172).  Bounded sample: ~15-25 s of wall time in all.
+        ncpu = args.cpu_threads or _usable_cpus()
+        model = _cpu_model()
+
+        def cpu_run(npairs, nthr):
+            wall, ok = 0.0, True
+            for i in range(npairs):
+                L0, R0 = Ls[i].cpu().numpy(), Rs[i].cpu().numpy()
+                t1 = time.perf_counter()
+                cpu = oracle.disparity_rows_mt(L0, R0, block, maxdisp, 0, H, nthr)  # one full pair
+                wall += time.perf_counter() - t1
+                ok = ok and bool(np.array_equal(cpu, out[i].cpu().numpy()))
+            return wall, ok
+
+        n1 = 1 if F >= 1 else 0                                   # one full pair single-threaded (~5-12 s)
+        w1, ok1 = cpu_run(n1, 1)
+        nn = min(F, max(2, min(64, ncpu)))                       # ~4-5 s of wall time at nproc threads (one pair per thread-equivalent)
+        wn, okn = cpu_run(nn, ncpu)
+        ok = ok1 and okn
+        res["cpu_baseline"] = {
+            "value": nn / wn, "unit": "pairs/s", "cores": ncpu, "kind": "port", "cpu_model": model,
+            "sample": f"{nn} full {W}x{H} pairs (frame seeds 1000..{1000 + nn - 1} of this rank), literal restatement of "
+                      f"pkg/despair sad.go:55-94 in C, {ncpu} threads over output.go row bands, {wn:.2f} s wall = {wn * ncpu:.0f} CPU-seconds",
+            "single_thread": {"value": n1 / w1 if w1 > 0 else None, "unit": "pairs/s", "cores": 1,
+                              "sample": f"{n1} full pair, same code, 1 thread, {w1:.2f} s"},
+            "gpu_output_matches": ok}
         if not ok:
             res["parity_error"] = "a GPU frame differs from the CPU oracle"
     print(json.dumps(res))

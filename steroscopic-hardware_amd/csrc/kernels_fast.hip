@@ -207,8 +207,17 @@ __device__ __forceinline__ void wg_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int P, int ND, int H, bool PK, bool W16 = false>
+template <int P, int ND, int H, bool PK, bool W16 = false, bool FL = false>
 struct Cw {                                         // P columns per lane: 4 (h <= 4) or 8 (h <= 15)
+  // FL: "fast-run float" variant of the unpacked layout (P = 8, ND = 8, h = 4..7).  Measured on MI355X
+  // (tools/ubench/valu_mix.hip, valu_rates2.hip): a fast-class instruction (v_add/v_sub_f32, also
+  // with a |x| source modifier) costs ~2.3 SIMD-cycles only inside a RUN of fast-class instructions;
+  // alone between slow-class ones (v_sad_*, DPP, v_min*, v_perm, ...) it costs the same ~4.2 as they do.
+  // Here every pixel and column sum is an f32 holding an exact small integer: |L-R| is v_sub_f32 +
+  // v_add_f32 |t| (two fast ops, long runs), the horizontal prefix / suffix chains are fast runs,
+  // the tie-break index rides in the fraction of the sums (key-in-sum, below), so the only slow-class
+  // work left per candidate is 1 DPP add per window and half a v_min3_f32.
+  static_assert(!FL || (!PK && !W16 && P == 8 && ND == 8 && H >= 4 && H <= 7), "float variant: P 8, ND 8, h 4..7");
   // PK: column sums of disparity pairs packed as u16 halves (window SAD < 65536, i.e. h <= 7)
   static_assert(!PK || (H <= 7 && ND % 4 == 0), "packed sums need (2h+1)^2 * 255 < 65536");
   static constexpr int NC = PK ? ND / 2 : ND;       // accumulator registers per column
@@ -235,16 +244,35 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // otherwise leaves room for one workgroup per CU: P = 8, h >= 7.
   static_assert(!W16 || (P == 8 && ND == 8), "u16 ring: whole 16-byte reads need P and ND multiples of 8");
   using Px = typename std::conditional<W16, unsigned short, unsigned>::type;
-  static constexpr int XOFF = W16 ? 7 : 3;          // dpad = nw*ND + XOFF keeps every lane's R operands 16-byte aligned
+  // SWZ: quad-swizzled ring rows for the u32 ring of the P = 8, ND = 8 variants.  A lane's operands
+  // are 8 (L) / 16 (R) consecutive pixels = 32-byte lane stride: as ds_read_b128 that is a 2-way bank
+  // conflict (lanes l and l+8 of one 16-lane service group hit the same banks; 45 % of the LDS cycles
+  // of config 5 were conflict cycles, profiles/r02_c5.md).  Each part (L, R) of a ring row is
+  // therefore stored as two halves: quads (4 pixels) with even index in the first half, odd ones in
+  // the second, so that every ds_read_b128 of a lane's operand set sees a 16-byte lane stride again.
+  static constexpr bool SWZ = (P == 8) && !W16 && (ND == 8);
+  static constexpr int XOFF = (W16 || SWZ) ? 7 : 3;  // dpad = nw*ND + XOFF keeps every lane's R operands 16-byte aligned (SWZ: on an even quad)
+  // physical position of logical pixel e within a part of len pixels (len % 8 == 0), and its inverse
+  static __device__ __forceinline__ int phys(int e, int len)
+  {
+    return SWZ ? ((((e >> 3) << 2) | (e & 3)) + ((e >> 2) & 1) * (len >> 1)) : e;
+  }
+  static __device__ __forceinline__ int logical(int f, int len)
+  {
+    if constexpr (!SWZ) return f;
+    const int hl = len >> 1, hi = f >= hl ? 1 : 0, t = f - hi * hl;
+    return ((t >> 2) << 3) | (hi << 2) | (t & 3);
+  }
+  struct Src { const Px* a; const Px* b; };           // operand block of a lane: even quads at a, odd quads at b (SWZ); else all at a
   static constexpr int MAXR = (TW + 4 * ND + 8 + 255) / 256;   // ... R elements per lane
   static constexpr bool NEED_MASK = PK && H > 5;    // packed h = 6, 7: 2*(2h+1)^2*255 does not fit u16
   static constexpr int NM = ND + P;                 // lane masks: one per (candidate - column), see run()
 
   // N ring pixels starting at a 16-byte aligned element -> one u32 register each.
   template <int N>
-  static __device__ __forceinline__ void load_px(const Px* src, unsigned (&out)[N])
+  static __device__ __forceinline__ void load_px(Src src, unsigned (&out)[N])
   {
-    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    const uint4* s4 = reinterpret_cast<const uint4*>(src.a);
     if constexpr (W16) {
       static_assert(N % 8 == 0, "");
 #pragma unroll
@@ -255,9 +283,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
       }
     } else {
       static_assert(N % 4 == 0, "");
+      const uint4* t4 = reinterpret_cast<const uint4*>(src.b);
 #pragma unroll
       for (int m = 0; m < N / 4; ++m) {
-        const uint4 v = s4[m];
+        const uint4 v = SWZ ? ((m & 1) ? t4[m >> 1] : s4[m >> 1]) : s4[m];
         out[4 * m] = v.x; out[4 * m + 1] = v.y; out[4 * m + 2] = v.z; out[4 * m + 3] = v.w;
       }
     }
@@ -265,10 +294,32 @@ struct Cw {                                         // P columns per lane: 4 (h 
 
   // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
   // lin/lout: this lane's P L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
-  static __device__ __forceinline__ void update_columns(unsigned (&C)[P][NC],
-                                                        const Px* lin, const Px* rin,
-                                                        const Px* lout, const Px* rout)
+  static __device__ __forceinline__ void update_columns(unsigned (&C)[P][NC], Src lin, Src rin, Src lout, Src rout)
   {
+    if constexpr (FL) {
+      {
+        unsigned li[P], ri[NRV];
+        load_px(lin, li);
+        load_px(rin, ri);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+          for (int q = 0; q < ND; ++q)
+            C[p][q] = __float_as_uint(__uint_as_float(C[p][q]) + __builtin_fabsf(__uint_as_float(li[p]) - __uint_as_float(ri[p + ND - 1 - q])));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        unsigned lo[P], ro[NRV];
+        load_px(lout, lo);
+        load_px(rout, ro);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+          for (int q = 0; q < ND; ++q)
+            C[p][q] = __float_as_uint(__uint_as_float(C[p][q]) - __builtin_fabsf(__uint_as_float(lo[p]) - __uint_as_float(ro[p + ND - 1 - q])));
+      }
+      return;
+    }
     {
       unsigned li[P], ri[NRV];
       load_px(lin, li);
@@ -321,10 +372,29 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // column sums here: lin/rxin point at this lane's L pixels and at the 16-byte aligned block whose
   // element XOFF is R column x0 - dx.  Pixels are plain bytes (packed) or pre-shifted (unpacked):
   // v_sad_u32 accumulates the right thing in both.
-  static __device__ __forceinline__ void extra_update(unsigned (&CX)[P][1], const Px* lin, const Px* rxin,
-                                                      const Px* lout, const Px* rxout)
+  static __device__ __forceinline__ void extra_update(unsigned (&CX)[P][1], Src lin, Src rxin, Src lout, Src rxout)
   {
-    constexpr int NX = W16 ? 16 : P + 4;                  // elements XOFF .. XOFF+P-1 are used
+    constexpr int NX = XOFF == 7 ? 16 : P + 4;            // elements XOFF .. XOFF+P-1 are used
+    if constexpr (FL) {
+      {
+        unsigned li[P], ri[NX];
+        load_px(lin, li);
+        load_px(rxin, ri);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          CX[p][0] = __float_as_uint(__uint_as_float(CX[p][0]) + __builtin_fabsf(__uint_as_float(li[p]) - __uint_as_float(ri[p + XOFF])));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        unsigned lo[P], ro[NX];
+        load_px(lout, lo);
+        load_px(rxout, ro);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          CX[p][0] = __float_as_uint(__uint_as_float(CX[p][0]) - __builtin_fabsf(__uint_as_float(lo[p]) - __uint_as_float(ro[p + XOFF])));
+      }
+      return;
+    }
     {
       unsigned li[P], ri[NX];
       load_px(lin, li);
@@ -442,6 +512,56 @@ struct Cw {                                         // P columns per lane: 4 (h 
     }
   }
 
+  // FL: window sums of one candidate as PURE sums of columns inside the window (no prefix
+  // differences: a valid window never mixes with a penalised column, so every partial sum of a valid
+  // window is an exactly representable integer + index fraction).  own part = prefix, suffix or whole
+  // lane; + suffix of the left lane and / or prefix of the right lane through one DPP add each.
+  template <int W>
+  static __device__ __forceinline__ void window_sums_fl(const unsigned (&C)[P][W], int q, float (&s)[P])
+  {
+    float ps[P + 1], sf[P];
+    ps[1] = __uint_as_float(C[0][q]);
+#pragma unroll
+    for (int k = 1; k < P; ++k) ps[k + 1] = ps[k] + __uint_as_float(C[k][q]);
+    sf[P - 1] = __uint_as_float(C[P - 1][q]);
+#pragma unroll
+    for (int k = P - 2; k >= 1; --k) sf[k] = sf[k + 1] + __uint_as_float(C[k][q]);
+    sf[0] = ps[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float own = (p - H <= 0 && p + H >= P - 1) ? ps[P] : (p - H <= 0 ? ps[p + H + 1] : sf[p - H]);
+      s[p] = own;
+      if (p - H < 0) s[p] += __uint_as_float(from_left(__float_as_uint(sf[P + p - H])));
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (p + H > P - 1) s[p] += __uint_as_float(from_right(__float_as_uint(ps[p + H - P + 1])));
+  }
+
+  template <int W>
+  static __device__ __forceinline__ void reduce_row_fl(const unsigned (&C)[P][W], unsigned (&best)[P])
+  {
+#pragma unroll
+    for (int q = 0; q + 2 <= W; q += 2) {
+      float sa[P], sb[P];
+      window_sums_fl(C, q, sa);
+      __builtin_amdgcn_sched_barrier(0);
+      window_sums_fl(C, q + 1, sb);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < P; ++p)        // inline asm: fminf() makes hipcc canonicalise every operand first (a v_max_f32 x, x each)
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(best[p]) : "v"(sa[p]), "v"(sb[p]));
+    }
+    if constexpr (W % 2 != 0) {
+      float sa[P];
+      window_sums_fl(C, W - 1, sa);
+#pragma unroll
+      for (int p = 0; p < P; ++p) asm("v_min_f32 %0, %0, %1" : "+v"(best[p]) : "v"(sa[p]));
+    }
+  }
+
   template <int MASK, int JOFS, int W>
   static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const unsigned long long (&M)[NM],
                                                     unsigned (&best)[P], unsigned dbase, int qn)
@@ -499,20 +619,21 @@ struct Cw {                                         // P columns per lane: 4 (h 
       lut[i] = (unsigned char)(j.raw ? min(i, 255) : (i * 255) / j.maxdisp);     // sad.go:91-93
     {
       const int yy = ys - H;                              // step 0's entering row -> slot 0
-      for (int i = tid; i < ROWW; i += nt) {
+      for (int i = tid; i < ROWW; i += nt) {                // i = physical position in the ring row
         const bool isR = i >= TW;
-        const int col = isR ? tx - a.dbase - a.dpad + (i - TW) : tx + i;
+        const int col = isR ? tx - a.dbase - a.dpad + logical(i - TW, RW) : tx + logical(i, TW);
         unsigned v = 0u;
         if (yy >= 0 && yy < j.h && col >= 0 && col < j.w)
           v = (unsigned)(isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride)[col];
-        ring[i] = (Px)(v << a.pixshift);
+        ring[i] = (Px)(FL ? __float_as_uint((float)v) : v << a.pixshift);
       }
     }
     __syncthreads();
 
     // ---- this wave's share of the row streaming and of the output -------------------------------
-    // L elements (= output pixels) [wv*shl, (wv+1)*shl), R elements [wv*shr, (wv+1)*shr); lane l
-    // takes elements l, l+64, ...  lcol / rcol: image column of the element, NOT_MINE otherwise.
+    // L positions (= output pixels) [wv*shl, (wv+1)*shl), R positions [wv*shr, (wv+1)*shr) of a ring
+    // row (physical positions: see SWZ); lane l takes positions l, l+64, ...  lcol / rcol: image column
+    // of the pixel stored there, NOT_MINE otherwise.
     // The packed variants fetch rows with raw buffer loads: resource = the row, vector offset = the
     // column, range-checked by the hardware against the row width -- columns left or right of the
     // image (and NOT_MINE, as unsigned) read as 0 without branches or address arithmetic.
@@ -524,12 +645,12 @@ struct Cw {                                         // P columns per lane: 4 (h 
 #pragma unroll
       for (int v = 0; v < MAXL; ++v) {
         const int i = il0 + 64 * v;
-        lcol[v] = (ln + 64 * v < a.shl && i < TW) ? tx + i : NOT_MINE;
+        lcol[v] = (ln + 64 * v < a.shl && i < TW) ? tx + logical(i, TW) : NOT_MINE;
       }
 #pragma unroll
       for (int v = 0; v < MAXR; ++v) {
         const int i = ir0 + 64 * v;
-        rcol[v] = (ln + 64 * v < a.shr && i < RW) ? tx - a.dbase - a.dpad + i : NOT_MINE;
+        rcol[v] = (ln + 64 * v < a.shr && i < RW) ? tx - a.dbase - a.dpad + logical(i, RW) : NOT_MINE;
       }
     };
     row_share(lane);
@@ -537,13 +658,13 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // values are recomputed in every step from a lane id the compiler cannot see through (a dozen
     // VALU instructions per step) instead of being held -- held, they were spilled to scratch in the
     // set-up code and reloaded in every step (14-21 VGPRs, 60-88 bytes of scratch per lane).
-    constexpr bool RECOMPUTE_SHARE = !PK && !X_NORECOMP;
+    constexpr bool RECOMPUTE_SHARE = !PK && !FL && !X_NORECOMP;
     unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
     auto load_row = [&](int yy) {
       if (yy >= 0 && yy < j.h) {
         const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * j.lstride;
         const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * j.rstride;
-        if constexpr (PK || X_BUFLOAD) {
+        if constexpr (PK || FL || X_BUFLOAD) {
           // one resource per row (scalar arithmetic): base = the row, num_records = its width
           const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lrow), 0, j.w, 0x00020000);
           const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(rrow), 0, j.w, 0x00020000);
@@ -569,10 +690,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
     auto land_row = [&](Px* dst) {
 #pragma unroll
       for (int v = 0; v < MAXL; ++v)
-        if (lcol[v] != NOT_MINE) dst[il0 + 64 * v] = (Px)(PK ? pfl[v] : pfl[v] << a.pixshift);
+        if (lcol[v] != NOT_MINE) dst[il0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfl[v]) : PK ? pfl[v] : pfl[v] << a.pixshift);
 #pragma unroll
       for (int v = 0; v < MAXR; ++v)
-        if (rcol[v] != NOT_MINE) dst[TW + ir0 + 64 * v] = (Px)(PK ? pfr[v] : pfr[v] << a.pixshift);
+        if (rcol[v] != NOT_MINE) dst[TW + ir0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfr[v]) : PK ? pfr[v] : pfr[v] << a.pixshift);
     };
     const unsigned kmask = (1u << a.ksh) - 1u;
     auto finalize = [&](int t) {                          // output row of step t, this wave's pixels
@@ -583,8 +704,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
 #pragma unroll
       for (int v = 0; v < MAXL; ++v) {
         if (lcol[v] != NOT_MINE) {
-          const int i = il0 + 64 * v, x = tx + i;
-          const int ri = (i % P) * RBP + i / P;
+          const int x = lcol[v], i = x - tx;                // i = column within the tile (>= 0)
+          const int ri = (i & (P - 1)) * RBP + (i >> (P == 8 ? 3 : 2));
           unsigned k = rb[ri];
           rb[ri] = KEY_INVALID;
           if (x >= ox0 && x < ox1) {
@@ -593,7 +714,12 @@ struct Cw {                                         // P columns per lane: 4 (h 
               a.kout[krow + (unsigned)(x - j.x0)] = k;
             } else {
               // x <= h: d = 0 is the only candidate (sad.go:66-69)
-              const unsigned d = x <= H ? 0u : min(k & kmask, (unsigned)j.maxdisp);
+              unsigned dk = k & kmask;
+              if constexpr (FL) {                           // key = window SAD (integer) + local candidate index / 256
+                const float kf = __uint_as_float(k);
+                dk = (unsigned)a.dbase + (unsigned)((kf - __builtin_floorf(kf)) * 256.0f + 0.5f);
+              }
+              const unsigned d = x <= H ? 0u : min(dk, (unsigned)j.maxdisp);
               orow[(unsigned)(x - j.ox)] = lut[d];
             }
           }
@@ -646,6 +772,12 @@ struct Cw {                                         // P columns per lane: 4 (h 
         if (!use_pen || !in) return 0u;
         if (d > j.maxdisp) return (j.w - 1 - col) % B1 == 0 ? PEN : 0u;
         return (col < d && (d - 1 - col) % B1 == 0) ? PEN : 0u;
+      } else if constexpr (FL) {
+        // f32 sums: the biased column class carries (candidate index within the pass) / 256 -- the sums
+        // stay exact while (2h+1)^2 * 255 * 256 < 2^24 (h <= 7) -- and a penalised column 2^16, above
+        // every valid window sum; a penalised sum need not be exact, it only has to lose
+        const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
+        return __float_as_uint((biased ? (float)(d - a.dbase) * (1.0f / 256.0f) : 0.0f) + ((in && (col < d || d > j.maxdisp)) ? 65536.0f : 0.0f));
       } else {
         const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
         return (biased ? (unsigned)d : 0u) + ((in && (col < d || d > j.maxdisp)) ? PEN : 0u);
@@ -670,9 +802,12 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const bool key_mask = !use_pen && max(ox0, 0) - H < min(dc + ND - 1 + (xtra ? 1 : 0), j.maxdisp);
 
     // this lane's operands inside a ring row (pixel index): L at lofs, R value m at rofs + m
-    const int lofs = P * lane;
-    const int rofs = TW + (a.dpad - dcl - (ND - 1)) + P * lane;       // 16-byte aligned by construction (dpad = nw*ND + XOFF)
-    const int rxofs = TW + (a.dpad - a.nw * ND - XOFF) + P * lane;    // extra candidate: R value of column p at +XOFF+p
+    // (SWZ: logical quad 2*lane + c + j of a part lives at quad lane + (c + j) / 2 of half (c + j) & 1;
+    //  c = (dpad - dcl - (ND-1)) / 4 = 2 * (nw - wv) is even, so even j read half 0 and odd j half 1)
+    const int lofs = SWZ ? 4 * lane : P * lane;
+    const int rofs = TW + (SWZ ? 4 * (a.nw - wv + lane) : (a.dpad - dcl - (ND - 1)) + P * lane);   // 16-byte aligned by construction (dpad = nw*ND + XOFF)
+    const int rxofs = TW + (SWZ ? 4 * lane : (a.dpad - a.nw * ND - XOFF) + P * lane);             // extra candidate: R value of column p at +XOFF+p
+    const int lhalf = SWZ ? TW / 2 : 0, rhalf = SWZ ? RW / 2 : 0;
 
     // ---- main loop: step t brings in image row ys-H+t (ring slot t % NR) ------------------------
     //   load    this wave's share of row t+1 (global -> registers; lands after the arithmetic)
@@ -698,19 +833,23 @@ struct Cw {                                         // P columns per lane: 4 (h 
       const Px* rout = ring + slot_out * ROWW;
       unsigned best[P];
 #pragma unroll
-      for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
+      for (int p = 0; p < P; ++p) best[p] = FL ? 0x7f800000u : KEY_INVALID;     // FL: +inf (keys are non-negative floats)
       const bool out_row = t >= 2 * H;
-      if (lane_valid) update_columns(C, rin + lofs, rin + rofs, rout + lofs, rout + rofs);
+      if (lane_valid) update_columns(C, Src{rin + lofs, rin + lofs + lhalf}, Src{rin + rofs, rin + rofs + rhalf},
+                                     Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rofs, rout + rofs + rhalf});
       if (out_row) {
-        if (NEED_MASK && key_mask) reduce_row<2, 0>(C, M, best, (unsigned)dc, qn);
+        if constexpr (FL) reduce_row_fl(C, best);
+        else if (NEED_MASK && key_mask) reduce_row<2, 0>(C, M, best, (unsigned)dc, qn);
         else reduce_row<0, 0>(C, M, best, (unsigned)dc, qn);
       }
       if (xtra) {                                         // the odd candidate dx (wave-uniform branch)
         __builtin_amdgcn_sched_barrier(0);
         if (lane_valid)
-          extra_update(CX, rin + lofs, rin + rxofs, rout + lofs, rout + rxofs);
+          extra_update(CX, Src{rin + lofs, rin + lofs + lhalf}, Src{rin + rxofs, rin + rxofs + rhalf},
+                       Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rxofs, rout + rxofs + rhalf});
         if (out_row) {
-          if constexpr (NEED_MASK) reduce_row<2, ND>(CX, M, best, (unsigned)dx, 1);   // also drops the empty high half
+          if constexpr (FL) reduce_row_fl(CX, best);
+          else if constexpr (NEED_MASK) reduce_row<2, ND>(CX, M, best, (unsigned)dx, 1);   // also drops the empty high half
           else reduce_row<0, 0>(CX, M, best, (unsigned)dx, 1);
         }
       }
@@ -735,10 +874,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
 
 
 // WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
-template <int P, int ND, int H, bool PK, int WB, bool W16>
-__global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK, W16>::run(a); }
+template <int P, int ND, int H, bool PK, int WB, bool W16, bool FL = false>
+__global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK, W16, FL>::run(a); }
 
-struct Plan { int p, nd, nw; bool pk, extra, w16; };
+struct Plan { int p, nd, nw; bool pk, extra, w16; bool fl = false; };
 struct Pass { Plan pl; int dbase; };              // candidates [dbase, dbase + nw*nd (+1)) of the job
 struct PassIo { int dbase; const unsigned* kin; unsigned* kout; int kw; };
 
@@ -802,7 +941,7 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
       const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
                        ((pk && h == 7) || (!pk && h >= 8 && maxdisp <= 255));
       // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
-      if ((size_t)(2 * h + 4) * (2 * 64 * p + nw * nd + (w16 ? 8 : 4)) * (w16 ? 2 : 4) + (size_t)2 * 72 * p * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
+      if ((size_t)(2 * h + 4) * (2 * 64 * p + nw * nd + ((w16 || (p == 8 && nd == 8)) ? 8 : 4)) * (w16 ? 2 : 4) + (size_t)2 * 72 * p * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
       const int slots = nw * nd;
       if (slots + 1 < count) continue;
       const bool extra = slots + 1 == count;
@@ -837,10 +976,24 @@ std::vector<Pass> plan_job(int h, int maxdisp, bool narrow)
   return memo;
 }
 
+#ifndef SADHIP_FCOL_DEFAULT
+#define SADHIP_FCOL_DEFAULT 0
+#endif
+
 std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
 {
   std::vector<Pass> passes;
   if (h < 1 || h > 15 || maxdisp < 1) return passes;
+  // the fast-run float variant: one pass of 4..8 waves x 8 candidates (+ the 8k+1-th on the last wave)
+  if (env_int("SADHIP_TUNE_FCOL", SADHIP_FCOL_DEFAULT) != 0 && h >= 4 && h <= 7 && maxdisp + 1 <= 65) {
+    const int count = maxdisp + 1;
+    int nw = (count - 1 + 7) / 8;                               // nw*8 + 1 >= count
+    if (nw < 4) nw = 4;
+    Plan pl{8, 8, nw, false, nw * 8 + 1 == count, false};
+    pl.fl = true;
+    passes.push_back(Pass{pl, 0});
+    return passes;
+  }
   for (int variant = (h <= 7 && !narrow && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; variant < 2; ++variant) {
     const bool pk = variant == 0;
     if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
@@ -870,10 +1023,11 @@ std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
 // dry: run every host-side check (instantiation exists, per-wave shares fit, LDS fits) and return
 // without launching -- what fast_supported() asks, so that a job the column-wave kernel cannot run
 // is routed to the generic kernel at PLANNING time and never by a silent fallback after a failure.
-template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false>
+template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false, bool FL = false>
 hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry)
 {
-  using K = Cw<P, ND, H, PK, W16>;
+  using K = Cw<P, ND, H, PK, W16, FL>;
+  if (FL && (io.kin || io.kout)) return hipErrorInvalidValue;   // float keys do not travel between passes
   CwArgs a{};
   a.j = j;
   a.nw = pl.nw;
@@ -926,7 +1080,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
     if (aa.kin) aa.kin += koff;
     if (aa.kout) aa.kout += koff;
     aa.nstrips = (int)nstrips;
-    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, FL>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -955,11 +1109,11 @@ int describe_fast(const Job& j, char* buf, int cap)
   for (size_t k = 0; k < passes.size(); ++k) {
     const Plan& pl = passes[k].pl;
     const int next = k + 1 < passes.size() ? passes[k + 1].dbase : j.maxdisp + 1;
-    const size_t lds = (size_t)(2 * h + 4) * (2 * 64 * pl.p + pl.nw * pl.nd + (pl.w16 ? 8 : 4)) * (pl.w16 ? 2 : 4) +
+    const size_t lds = (size_t)(2 * h + 4) * (2 * 64 * pl.p + pl.nw * pl.nd + ((pl.w16 || (pl.p == 8 && pl.nd == 8)) ? 8 : 4)) * (pl.w16 ? 2 : 4) +
                        (size_t)2 * 72 * pl.p * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15);
     if (buf && at < cap)
-      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d lds=%zu\n",
-                     passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, lds);
+      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d fl=%d lds=%zu\n",
+                     passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, (int)pl.fl, lds);
   }
   return (int)passes.size();
 }
@@ -967,6 +1121,11 @@ int describe_fast(const Job& j, char* buf, int cap)
 static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry = false)
 {
   const int h = j.block / 2;
+#ifdef SADHIP_TUNING            // the float variant is an experiment (slower than the packed kernels): diagnostics build only
+#define SADHIP_FL(HH) if (pl.fl && h == HH) return launch_t<8, 8, HH, false, 1024, false, true>(j, pl, io, s, dry)
+  SADHIP_FL(4); SADHIP_FL(5); SADHIP_FL(6); SADHIP_FL(7);
+#endif
+  if (pl.fl) return hipErrorInvalidValue;
 #ifdef SADHIP_EXPERIMENT        // resource-usage experiments: only the instantiations under study (seconds to compile)
   if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry);
   if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry);

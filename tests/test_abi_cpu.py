@@ -201,7 +201,7 @@ def test_planner_invariants_over_the_parameter_space():
                 seen.add((ps["p"], ps["nd"], ps["packed"], ps["w16"]))
             assert at in (0, maxdisp + 1)
     assert {(4, 16, 1, 0), (8, 8, 1, 1), (8, 8, 0, 1), (8, 12, 1, 0), (8, 4, 0, 0)} <= seen
-    assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0,
+    assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0, fl=0,
                                                          lds=capi.plan_describe(1920, 1080, 9, 64)[0]["lds"])]
 
 
