@@ -55,10 +55,25 @@ def _cpu_model():
 
 
 def _usable_cpus():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when one
+    is set (a GPU box hands each tenant a share of its host cores)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def _time_reference_c(ctx, sha):
@@ -253,7 +268,11 @@ def main():
         # CPU baseline: the literal C restatement of pkg/despair sad.go:55-94 on this box's
         # host cores, same frames as the GPU: one thread, then every core this process may use (row bands
         # like output.go:172).  Bounded sample: ~15-25 s of wall time in all.
-        ncpu = args.cpu_threads or _usable_cpus()
+        # "all cores" = this process's share of the host: affinity / cgroup quota, and at most 16 -- a
+        # one-GPU box of this pool shares its host with other tenants and 16 cores is the per-GPU share
+        # (256 threads on the shared 128-core host measured SLOWER than 16: 3.1 vs 3.7 pairs/s)
+        ncpu = args.cpu_threads or min(_usable_cpus(), 16)
+        host_cpus = os.cpu_count() or ncpu
         model = _cpu_model()
 
         def cpu_run(npairs, nthr):
@@ -272,7 +291,7 @@ def main():
         wn, okn = cpu_run(nn, ncpu)
         ok = ok1 and okn
         res["cpu_baseline"] = {
-            "value": nn / wn, "unit": "pairs/s", "cores": ncpu, "kind": "port", "cpu_model": model,
+            "value": nn / wn, "unit": "pairs/s", "cores": ncpu, "kind": "port", "cpu_model": model, "host_logical_cpus": host_cpus,
             "sample": f"{nn} full {W}x{H} pairs (frame seeds 1000..{1000 + nn - 1} of this rank), literal restatement of "
                       f"pkg/despair sad.go:55-94 in C, {ncpu} threads over output.go row bands, {wn:.2f} s wall = {wn * ncpu:.0f} CPU-seconds",
             "single_thread": {"value": n1 / w1 if w1 > 0 else None, "unit": "pairs/s", "cores": 1,

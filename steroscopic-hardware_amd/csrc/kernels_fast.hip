@@ -275,11 +275,15 @@ struct Cw {                                         // P columns per lane: 4 (h 
     const uint4* s4 = reinterpret_cast<const uint4*>(src.a);
     if constexpr (W16) {
       static_assert(N % 8 == 0, "");
+      // the mask lives in a VGPR: v_and_b32 with the 32-bit literal 0xffff is a slow-class instruction
+      // (4.2 cycles), with a register operand it is fast-class (2.3 in a run) -- tools/ubench/valu_rates.hip
+      unsigned lo16 = 0xffffu;
+      asm("" : "+v"(lo16));
 #pragma unroll
       for (int m = 0; m < N / 8; ++m) {
         const uint4 v = s4[m];
-        out[8 * m] = v.x & 0xffffu; out[8 * m + 1] = v.x >> 16; out[8 * m + 2] = v.y & 0xffffu; out[8 * m + 3] = v.y >> 16;
-        out[8 * m + 4] = v.z & 0xffffu; out[8 * m + 5] = v.z >> 16; out[8 * m + 6] = v.w & 0xffffu; out[8 * m + 7] = v.w >> 16;
+        out[8 * m] = v.x & lo16; out[8 * m + 1] = v.x >> 16; out[8 * m + 2] = v.y & lo16; out[8 * m + 3] = v.y >> 16;
+        out[8 * m + 4] = v.z & lo16; out[8 * m + 5] = v.z >> 16; out[8 * m + 6] = v.w & lo16; out[8 * m + 7] = v.w >> 16;
       }
     } else {
       static_assert(N % 4 == 0, "");
@@ -640,25 +644,36 @@ struct Cw {                                         // P columns per lane: 4 (h 
     constexpr int NOT_MINE = (int)0x80000000;
     int il0, ir0;
     int lcol[MAXL], rcol[MAXR];
+    // The unpacked variants run at their 128-register limit: held across the row loop, these
+    // loop-invariant per-lane values were spilled to scratch in the set-up code and reloaded in every
+    // step (14-21 VGPRs, 60-88 bytes of scratch per lane in round 1).  There (RECOMPUTE_SHARE) the
+    // columns are re-derived in every step from a lane id the compiler cannot see through (one add
+    // each) and "this position is mine" is a wave-uniform 64-bit lane mask per position, held in SGPRs
+    // and applied as the branch condition itself (s_and_saveexec, no vector instruction).
+    constexpr bool RECOMPUTE_SHARE = !PK && !FL && !X_NORECOMP;
+    unsigned long long mineL[MAXL], mineR[MAXR];
     auto row_share = [&](int ln) {                        // ln = lane
       il0 = wv * a.shl + ln; ir0 = wv * a.shr + ln;
 #pragma unroll
       for (int v = 0; v < MAXL; ++v) {
         const int i = il0 + 64 * v;
-        lcol[v] = (ln + 64 * v < a.shl && i < TW) ? tx + logical(i, TW) : NOT_MINE;
+        const int col = tx + logical(i, TW);
+        lcol[v] = (RECOMPUTE_SHARE || (ln + 64 * v < a.shl && i < TW)) ? col : NOT_MINE;
       }
 #pragma unroll
       for (int v = 0; v < MAXR; ++v) {
         const int i = ir0 + 64 * v;
-        rcol[v] = (ln + 64 * v < a.shr && i < RW) ? tx - a.dbase - a.dpad + logical(i, RW) : NOT_MINE;
+        const int col = tx - a.dbase - a.dpad + logical(i, RW);
+        rcol[v] = (RECOMPUTE_SHARE || (ln + 64 * v < a.shr && i < RW)) ? col : NOT_MINE;
       }
     };
     row_share(lane);
-    // The unpacked variants run at their 128-register limit: there these loop-invariant per-lane
-    // values are recomputed in every step from a lane id the compiler cannot see through (a dozen
-    // VALU instructions per step) instead of being held -- held, they were spilled to scratch in the
-    // set-up code and reloaded in every step (14-21 VGPRs, 60-88 bytes of scratch per lane).
-    constexpr bool RECOMPUTE_SHARE = !PK && !FL && !X_NORECOMP;
+#pragma unroll
+    for (int v = 0; v < MAXL; ++v) mineL[v] = __builtin_amdgcn_ballot_w64(lane + 64 * v < a.shl && il0 + 64 * v < TW);
+#pragma unroll
+    for (int v = 0; v < MAXR; ++v) mineR[v] = __builtin_amdgcn_ballot_w64(lane + 64 * v < a.shr && ir0 + 64 * v < RW);
+    auto mine_l = [&](int v) -> bool { if constexpr (RECOMPUTE_SHARE) return __builtin_amdgcn_inverse_ballot_w64(mineL[v]); else return lcol[v] != NOT_MINE; };
+    auto mine_r = [&](int v) -> bool { if constexpr (RECOMPUTE_SHARE) return __builtin_amdgcn_inverse_ballot_w64(mineR[v]); else return rcol[v] != NOT_MINE; };
     unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
     auto load_row = [&](int yy) {
       if (yy >= 0 && yy < j.h) {
@@ -690,10 +705,10 @@ struct Cw {                                         // P columns per lane: 4 (h 
     auto land_row = [&](Px* dst) {
 #pragma unroll
       for (int v = 0; v < MAXL; ++v)
-        if (lcol[v] != NOT_MINE) dst[il0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfl[v]) : PK ? pfl[v] : pfl[v] << a.pixshift);
+        if (mine_l(v)) dst[il0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfl[v]) : PK ? pfl[v] : pfl[v] << a.pixshift);
 #pragma unroll
       for (int v = 0; v < MAXR; ++v)
-        if (rcol[v] != NOT_MINE) dst[TW + ir0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfr[v]) : PK ? pfr[v] : pfr[v] << a.pixshift);
+        if (mine_r(v)) dst[TW + ir0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfr[v]) : PK ? pfr[v] : pfr[v] << a.pixshift);
     };
     const unsigned kmask = (1u << a.ksh) - 1u;
     auto finalize = [&](int t) {                          // output row of step t, this wave's pixels
@@ -703,7 +718,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
       const size_t krow = ((size_t)f * (j.y1 - j.y0) + (y - j.y0)) * a.kw;
 #pragma unroll
       for (int v = 0; v < MAXL; ++v) {
-        if (lcol[v] != NOT_MINE) {
+        if (mine_l(v)) {
           const int x = lcol[v], i = x - tx;                // i = column within the tile (>= 0)
           const int ri = (i & (P - 1)) * RBP + (i >> (P == 8 ? 3 : 2));
           unsigned k = rb[ri];
@@ -1037,8 +1052,16 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   a.dbase = io.dbase; a.kin = io.kin; a.kout = io.kout; a.kw = io.kw;
   a.dpad = pl.nw * ND + K::XOFF;                              // keeps every lane's R operands 16-byte aligned
   const int RW = K::TW + a.dpad + 1;
-  a.shl = (K::TW + pl.nw - 1) / pl.nw;
-  a.shr = (RW + pl.nw - 1) / pl.nw;
+  // Row streaming and output are shared by the waves.  The wave that carries the odd candidate does
+  // ~12 % more arithmetic per row than the others (9 candidates against 8) and every wave waits for it at
+  // the row barrier -- with one or two workgroups per CU (P = 8) nothing else fills that wait.  Where the
+  // shares still fit the registers reserved for them, that wave (the last one) takes no share at all:
+  // its streaming + output work, about as many instructions as its extra candidate, goes to the others.
+  int sharers = pl.nw;
+  if (pl.extra && pl.nw > 1 && (K::TW + pl.nw - 2) / (pl.nw - 1) <= 64 * K::MAXL && (RW + pl.nw - 2) / (pl.nw - 1) <= 64 * K::MAXR)
+    sharers = pl.nw - 1;
+  a.shl = (K::TW + sharers - 1) / sharers;
+  a.shr = (RW + sharers - 1) / sharers;
   if (a.shl > 64 * K::MAXL || a.shr > 64 * K::MAXR) return hipErrorInvalidValue;   // cannot happen for nw >= 4
   const int r = j.w % P;
   a.tx0 = r == 0 ? 0 : r - P;

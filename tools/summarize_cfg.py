@@ -11,6 +11,7 @@ VALU wave-instructions per 64 candidate evaluations, SIMD-cycles per VALU instru
 import collections
 import csv
 import os
+import re
 import sys
 
 tag, out = sys.argv[1], sys.argv[2]
@@ -47,9 +48,12 @@ if os.path.exists(tr):
         big = [r for r in rows if r["_d"] > thr]
         by_kernel = collections.defaultdict(list)
         for r in big:
-            by_kernel[r["Kernel_Name"].split("(")[0][-60:]].append(r)
+            by_kernel[re.sub(r"^.*(k_\w+<[^>]*>).*$", r"\1", r["Kernel_Name"])[:70]].append(r)
         lines += ["## `--kernel-trace` (batched launches of the disparity kernel)", "",
-                  "| kernel | launches | avg us | min us | arch VGPRs | LDS bytes | scratch | workgroup | grid (threads) |", "|---|---|---|---|---|---|---|---|---|"]
+                  "(The trace's VGPR / LDS columns are what rocprofv3 prints for the dispatch packet: LDS is 0 because the kernel's LDS is "
+                  "dynamic, and its VGPR figure is the allocation granule, not the compiler's count -- see `hipcc -Rpass-analysis=kernel-resource-usage` "
+                  "in `steroscopic-hardware_amd/lib/kernels_fast.remarks` / DESIGN.md for registers, scratch and LDS per variant.)", "",
+                  "| kernel | launches | avg us | min us | trace VGPR field | trace LDS field | scratch | workgroup | grid (threads) |", "|---|---|---|---|---|---|---|---|---|"]
         tot = 0.0
         for k, rs in by_kernel.items():
             d = [r["_d"] for r in rs]
@@ -67,7 +71,8 @@ if os.path.exists(st):
     lines += ["", "`--stats` rows of the disparity kernels:", "", "| kernel | calls | total ns | avg ns | min ns | max ns |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(st)):
         if is_disp(r["Name"]):
-            lines.append(f"| `{r['Name'].split('(')[0][-60:]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |")
+            kname = re.sub(r"^.*(k_[a-z_]+<[^>]*>).*$", r"\1", r["Name"])[:70]
+            lines.append(f"| `{kname}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |")
 
 pm = {}
 for p in ("pmc_sq", "pmc_fetch", "pmc_write"):

@@ -56,7 +56,7 @@ def ensure_asm(path):
         return
     os.makedirs(os.path.dirname(path), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-command-line-argument",
-                           "--cuda-device-only", "-S", "-o", path, os.path.join(CSRC, "kernels_fast.hip")])
+                           "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", path, os.path.join(CSRC, "kernels_fast.hip")])
 
 
 def classify(line):
@@ -158,7 +158,7 @@ def main():
     P, ND, H, PK, WB, W16 = (int(v) for v in a.variant)
     ensure_asm(a.asm)
     asm = open(a.asm).read()
-    sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}EEEvNS0_6CwArgsE"
+    sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb0EEEvNS0_6CwArgsE"
     blocks = analyse(kernel_body(asm, sym))
     main_ins, xtra_ins = [], []
     for b in blocks:
