@@ -437,6 +437,30 @@ def test_device_resident_batch(ctx):
         assert np.array_equal(out[i].cpu().numpy(), _expect(L, R, 9, 64))
 
 
+def test_multi_pass_batch_beyond_one_grid(ctx):
+    """a multi-pass job (D + 1 > 129 candidates: a u32 key per pixel travels between the
+    passes) over more frames than one sub-launch covers (32768): the key rows of the later
+    sub-launches must be their own.  33 000 tiny frames, D = 130, device-resident."""
+    import torch
+    n, w, h, block, D = 33000, 150, 6, 3, 130
+    assert len(capi.plan_describe(w, h, block, D)) >= 2
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Ls = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda", generator=g)
+    Rs = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda", generator=g)
+    out = torch.empty_like(Ls)
+    ctx.disparity_dev(Ls, Rs, out, block, D)
+    torch.cuda.synchronize()
+    assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+    for i in (0, 1, 32767, 32768, 32769, n - 1):
+        L, R = Ls[i].cpu().numpy(), Rs[i].cpu().numpy()
+        assert np.array_equal(out[i].cpu().numpy(), _expect(L, R, block, D)), i
+    # every frame against the generic kernel (independent second implementation), on the device
+    gen = torch.empty_like(Ls)
+    ctx.disparity_dev(Ls, Rs, gen, block, D, capi.FLAG_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    assert torch.equal(out, gen)
+
+
 # ---- SumAbsoluteDifferences (sad.go:205-244), incl. the independent right clamp ----------------
 def test_sad_windows_kats_and_clamps(ctx, hwfx):
     wl = np.ascontiguousarray(hwfx["winL"].reshape(15, 15)); wr = np.ascontiguousarray(hwfx["winR"].reshape(15, 15))
