@@ -442,7 +442,7 @@ def test_multi_pass_batch_beyond_one_grid(ctx):
     passes) over more frames than one sub-launch covers (32768): the key rows of the later
     sub-launches must be their own.  33 000 tiny frames, D = 130, device-resident."""
     import torch
-    n, w, h, block, D = 33000, 150, 6, 3, 130
+    n, w, h, block, D = 33000, 230, 6, 3, 200
     assert len(capi.plan_describe(w, h, block, D)) >= 2
     g = torch.Generator(device="cuda").manual_seed(5)
     Ls = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda", generator=g)
