@@ -76,6 +76,11 @@ struct CwArgs {
   const unsigned* kin;     // keys so far, or nullptr (first pass)
   unsigned* kout;          // where to leave the keys, or nullptr (last pass: write the output)
   int kw;                  // u32 per key row (= x1 - x0); key of (f, y, x) at (f*rows + y-y0)*kw + x-x0
+#ifdef SADHIP_STAMPS
+  // stamps build only (make stamps): per-wave sums of shader-clock ticks spent in the five phases of a row
+  // step (update, reduce, land, output, barrier wait) + the step count, at stamps[(workgroup*16 + wave)*8 + k]
+  unsigned long long* stamps;
+#endif
 };
 
 constexpr unsigned KEY_INVALID = 0xffffffffu;
@@ -833,12 +838,22 @@ struct Cw {                                         // P columns per lane: 4 (h 
     //   barrier
     const int nsteps = (ye - ys) + 2 * H;
     int slot_in = 0;
+#ifdef SADHIP_STAMPS
+    unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_prev = 0;
+#define SADHIP_STAMP(K) do { if (a.stamps) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                             st_sum[K] += now_ - st_prev; st_prev = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define SADHIP_STAMP0() do { if (a.stamps) st_prev = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SADHIP_STAMP(K) do {} while (0)
+#define SADHIP_STAMP0() do {} while (0)
+#endif
     for (int t = 0; t < nsteps; ++t) {
       if constexpr (RECOMPUTE_SHARE) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         row_share(ln);
       }
+      SADHIP_STAMP0();
       // (also in the last step: one harmless row more keeps loads and landings unconditional)
       load_row(ys - H + t + 1);
       const int so = slot_in + 2;                         // row t-(2h+1): NR - (2h+1) = 2 slots ahead
@@ -852,6 +867,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
       const bool out_row = t >= 2 * H;
       if (lane_valid) update_columns(C, Src{rin + lofs, rin + lofs + lhalf}, Src{rin + rofs, rin + rofs + rhalf},
                                      Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rofs, rout + rofs + rhalf});
+      SADHIP_STAMP(0);
       if (out_row) {
         if constexpr (FL) reduce_row_fl(C, best);
         else if (NEED_MASK && key_mask) reduce_row<2, 0>(C, M, best, (unsigned)dc, qn);
@@ -877,13 +893,26 @@ struct Cw {                                         // P columns per lane: 4 (h 
       // itself hipcc waits inside each lane-masked store block of land_row and, unable to prove that
       // one of them always runs, again at the loop head -- where vmcnt(0) also waits for the output
       // bytes stored at the end of the previous step (a memory round trip per row and wave).
+      SADHIP_STAMP(1);
       __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0); expcnt / lgkmcnt untouched
       land_row(ring + sn * ROWW);
+      SADHIP_STAMP(2);
       if (t - 1 >= 2 * H) finalize(t - 1);
+      SADHIP_STAMP(3);
       wg_barrier();
+      SADHIP_STAMP(4);
       slot_in = sn;
     }
     finalize(nsteps - 1);
+#ifdef SADHIP_STAMPS
+    if (a.stamps && lane == 0) {
+      unsigned long long* o = a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wv) * 8;
+      for (int k = 0; k < 5; ++k) o[k] = st_sum[k];
+      o[5] = (unsigned long long)nsteps;
+      o[6] = xtra ? 1 : 0;
+      o[7] = (unsigned long long)tile;
+    }
+#endif
   }
 };
 
@@ -908,7 +937,7 @@ int env_int(const char* name, int dflt)
     static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
-                                        "SADHIP_TUNE_FCOL"};
+                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -947,7 +976,7 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
   const int nd_max = p == 4 ? 24 : ((pk && h <= 5) ? 12 : 8);
   for (int nd = 4; nd <= nd_max; nd += 4) {
     if (force_nd && force_nd != nd) continue;
-    for (int nw = 4; nw <= 16; ++nw) {
+    for (int nw = 4; nw <= 16; ++nw) {                          // (two-wave workgroups for D <= 48 measured 25-35 % slower)
       if (force_nw && force_nw != nw) continue;
       if (p == 4 && nw > 8) continue;                           // measured: 11-16 waves (one workgroup per CU) lose ~10 % to passes of 8 waves
       if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
@@ -1103,9 +1132,43 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
     if (aa.kin) aa.kin += koff;
     if (aa.kout) aa.kout += koff;
     aa.nstrips = (int)nstrips;
+#ifdef SADHIP_STAMPS
+    const size_t nwg = (size_t)nstrips * aa.j.n * ntiles;
+    aa.stamps = nullptr;
+    if (env_int("SADHIP_TUNE_STAMPS", 0)) {
+      if (hipMalloc((void**)&aa.stamps, nwg * 16 * 8 * sizeof(unsigned long long)) != hipSuccess) aa.stamps = nullptr;
+      else (void)hipMemsetAsync(aa.stamps, 0, nwg * 16 * 8 * sizeof(unsigned long long), s);
+    }
+#endif
     hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, FL>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+#ifdef SADHIP_STAMPS
+    if (aa.stamps) {                                      // average ticks per row step and phase, by wave class
+      (void)hipStreamSynchronize(s);
+      std::vector<unsigned long long> h(nwg * 16 * 8);
+      (void)hipMemcpy(h.data(), aa.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      (void)hipFree(aa.stamps);
+      static const char* const nm[5] = {"update", "reduce", "land(+vmcnt wait)", "output", "barrier wait"};
+      double sum[3][5] = {}, steps[3] = {};               // class 0: ordinary wave, 1: extra-candidate wave, 2: waves of tile 0
+      for (size_t g = 0; g < nwg; ++g)
+        for (int w = 0; w < pl.nw; ++w) {
+          const unsigned long long* o = &h[(g * 16 + w) * 8];
+          if (!o[5]) continue;
+          const int c = o[7] == (unsigned long long)a.tile0 ? 2 : (o[6] ? 1 : 0);
+          for (int k = 0; k < 5; ++k) sum[c][k] += (double)o[k];
+          steps[c] += (double)o[5];
+        }
+      for (int c = 0; c < 3; ++c) {
+        if (steps[c] == 0) continue;
+        double tot = 0; for (int k = 0; k < 5; ++k) tot += sum[c][k];
+        fprintf(stderr, "sadhip stamps [%s] P%d ND%d H%d nw%d: %.0f ticks/step:", c == 0 ? "wave" : c == 1 ? "extra-candidate wave" : "leftmost-tile waves",
+                P, ND, H, pl.nw, tot / steps[c]);
+        for (int k = 0; k < 5; ++k) fprintf(stderr, "  %s %.0f (%.0f%%)", nm[k], sum[c][k] / steps[c], 100.0 * sum[c][k] / tot);
+        fprintf(stderr, "\n");
+      }
+    }
+#endif
   }
   return hipSuccess;
 }
