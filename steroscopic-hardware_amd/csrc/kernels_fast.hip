@@ -1108,7 +1108,10 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   // 24.2): when the batch alone fills the chip, cut strips down to ~48h rows (warm-up <= 4 %) while
   // the grid stays <= ~4096 workgroups.
   const long base = (long)ntiles * j.n;
-  const long want = env_int("SADHIP_TUNE_WGS", 512);          // tuning aids
+  // Small batches (the WebUI's case: one pair per call): a strip costs 2h warm-up rows, a second workgroup on
+  // a CU slows the first.  Measured single 1080p pairs: B9 (P = 4, five 4-wave workgroups fit a CU) 64.8 /
+  // 53.4 / 67.7 us at 256 / 512 / 768 workgroups; B16 (P = 8, two 8-wave workgroups fit) 82.8 / 123.2 / 117.6.
+  const long want = env_int("SADHIP_TUNE_WGS", P == 4 ? 512 : 256);
   const long rows_target = env_int("SADHIP_TUNE_ROWS", 48 * H), wg_max = env_int("SADHIP_TUNE_WGMAX", 4096);
   long nstrips = (want + base - 1) / base;
   if (base >= want) nstrips = std::max<long>(1, std::min<long>(rows / rows_target, wg_max / base));

@@ -180,6 +180,17 @@ def RunSad(left, right, blockSize, maxDisparity):
         return c.disparity(left, right, blockSize, maxDisparity)
 
 
+def RunSadPixels(left_pix, right_pix, blockSize, maxDisparity):
+    """The in-memory handoff of SURVEY 8 f-3 for decoded RGB(A) pictures (HxWx3 or HxWx4 uint8, as
+    png.Decode leaves an *image.NRGBA / opaque RGB): one sadhip_disparity_rgba_u8 call -- one upload per
+    image, the Go luminance (gray.go:43-58) on the device, no host gray plane -- instead of LoadPNG's gray
+    conversion followed by RunSad's second upload.  Sets the global parameters like RunSad (sad.go:123-126)."""
+    SetDefaultParams(Parameters(BlockSize=blockSize, MaxDisparity=maxDisparity))
+    h, w = left_pix.shape[:2]
+    with _context(w, h) as c:
+        return c.disparity_rgba(left_pix, right_pix, blockSize, maxDisparity)
+
+
 def SumAbsoluteDifferences(left, right, leftX, leftY, rightX, rightY, blockSize):
     """sad.go:205-244 (one query through the batched device entry point)."""
     h, w = left.shape
