@@ -874,6 +874,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
         else reduce_row<0, 0>(C, M, best, (unsigned)dc, qn);
       }
       if (xtra) {                                         // the odd candidate dx (wave-uniform branch)
+        asm volatile("; SADHIP_XTRA_BEGIN (tools/valu_budget.py counts this path separately)");
         __builtin_amdgcn_sched_barrier(0);
         if (lane_valid)
           extra_update(CX, Src{rin + lofs, rin + lofs + lhalf}, Src{rin + rxofs, rin + rxofs + rhalf},
@@ -883,6 +884,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
           else if constexpr (NEED_MASK) reduce_row<2, ND>(CX, M, best, (unsigned)dx, 1);   // also drops the empty high half
           else reduce_row<0, 0>(CX, M, best, (unsigned)dx, 1);
         }
+        asm volatile("; SADHIP_XTRA_END");
       }
       if (out_row) {
         unsigned* rb = rowbest + (t & 1) * RBW + lane;
@@ -922,6 +924,15 @@ template <int P, int ND, int H, bool PK, int WB, bool W16, bool FL = false>
 __global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK, W16, FL>::run(a); }
 
 struct Plan { int p, nd, nw; bool pk, extra, w16; bool fl = false; };
+
+// LDS bytes of one workgroup of a plan (the layout at the top of Cw::run): 2h+3 ring rows and the
+// row of zeros, two row-best buffers, the output LUT.
+inline size_t plan_lds_bytes(const Plan& pl, int h, int maxdisp)
+{
+  const bool swz = pl.p == 8 && !pl.w16 && pl.nd == 8;
+  const size_t tw = 64 * (size_t)pl.p, rw = tw + (size_t)pl.nw * pl.nd + ((pl.w16 || swz) ? 7 : 3) + 1, roww = tw + rw;
+  return (size_t)(2 * h + 4) * roww * (pl.w16 ? 2 : 4) + (size_t)2 * 72 * pl.p * 4 + (size_t)((maxdisp + 1 + 15) & ~15);
+}
 struct Pass { Plan pl; int dbase; };              // candidates [dbase, dbase + nw*nd (+1)) of the job
 struct PassIo { int dbase; const unsigned* kin; unsigned* kout; int kw; };
 
@@ -985,7 +996,7 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
       const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
                        ((pk && h == 7) || (!pk && h >= 8 && maxdisp <= 255));
       // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
-      if ((size_t)(2 * h + 4) * (2 * 64 * p + nw * nd + ((w16 || (p == 8 && nd == 8)) ? 8 : 4)) * (w16 ? 2 : 4) + (size_t)2 * 72 * p * 4 + (size_t)maxdisp + 16 > (size_t)160 * 1024) continue;
+      if (plan_lds_bytes(Plan{p, nd, nw, pk, false, w16}, h, maxdisp) > (size_t)160 * 1024) continue;
       const int slots = nw * nd;
       if (slots + 1 < count) continue;
       const bool extra = slots + 1 == count;
@@ -1120,9 +1131,10 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   if (nstrips < 1) nstrips = 1;
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
-  const int ROWW = K::TW + RW;
-  const size_t lds = (size_t)(K::NR + 1) * ROWW * sizeof(typename K::Px) + (size_t)K::NB * K::RBW * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15)
-                     + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
+  static_assert(K::NR == 2 * H + 3 && K::NB == 2 && K::RBW == 72 * P && K::XOFF == ((W16 || K::SWZ) ? 7 : 3), "plan_lds_bytes mirrors Cw");
+  Plan plk = pl; plk.p = P; plk.nd = ND; plk.pk = PK; plk.w16 = W16; plk.fl = FL;
+  const size_t lds = plan_lds_bytes(plk, H, j.maxdisp) + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
+  if (lds < (size_t)(K::NR + 1) * (K::TW + RW) * sizeof(typename K::Px)) return hipErrorInvalidValue;   // (cannot happen: same formula)
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (dry) return hipSuccess;
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
@@ -1198,8 +1210,7 @@ int describe_fast(const Job& j, char* buf, int cap)
   for (size_t k = 0; k < passes.size(); ++k) {
     const Plan& pl = passes[k].pl;
     const int next = k + 1 < passes.size() ? passes[k + 1].dbase : j.maxdisp + 1;
-    const size_t lds = (size_t)(2 * h + 4) * (2 * 64 * pl.p + pl.nw * pl.nd + ((pl.w16 || (pl.p == 8 && pl.nd == 8)) ? 8 : 4)) * (pl.w16 ? 2 : 4) +
-                       (size_t)2 * 72 * pl.p * 4 + (size_t)((j.maxdisp + 1 + 15) & ~15);
+    const size_t lds = plan_lds_bytes(pl, h, j.maxdisp);
     if (buf && at < cap)
       at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d fl=%d lds=%zu\n",
                      passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, (int)pl.fl, lds);

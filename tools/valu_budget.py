@@ -50,13 +50,13 @@ def source_digest():
     return h.hexdigest()[:16]
 
 
-def ensure_asm(path):
+def ensure_asm(path, defs=()):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
     if os.path.exists(path) and os.path.getmtime(path) >= max(os.path.getmtime(f) for f in srcs):
         return
     os.makedirs(os.path.dirname(path), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-command-line-argument",
-                           "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", path, os.path.join(CSRC, "kernels_fast.hip")])
+                           "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", path, os.path.join(CSRC, "kernels_fast.hip")] + ["-D" + d for d in defs])
 
 
 def classify(line):
@@ -109,6 +109,9 @@ def analyse(lines):
         if m:
             labels[m.group(1)] = len(ins)
             continue
+        if "SADHIP_XTRA_BEGIN" in ln or "SADHIP_XTRA_END" in ln:
+            ins.append(";" + ("XB" if "BEGIN" in ln else "XE"))       # markers the kernel emits around the extra-candidate path
+            continue
         if ln.startswith("\t") and not ln.lstrip().startswith((".", ";")):
             ins.append(ln.strip())
     best = None
@@ -154,20 +157,21 @@ def main():
     ap.add_argument("--asm", default=os.path.join(LIBD, "kernels_fast.s"))
     ap.add_argument("--json")
     ap.add_argument("--blocks", action="store_true")
+    ap.add_argument("-D", dest="defs", action="append", default=[], help="extra -D for the compile (e.g. SADHIP_EXPERIMENT: only the kernels under study)")
     a = ap.parse_args()
     P, ND, H, PK, WB, W16 = (int(v) for v in a.variant)
-    ensure_asm(a.asm)
+    ensure_asm(a.asm, a.defs)
     asm = open(a.asm).read()
     sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb0EEEvNS0_6CwArgsE"
     blocks = analyse(kernel_body(asm, sym))
     main_ins, xtra_ins = [], []
+    # the extra-candidate path = the blocks from the kernel's SADHIP_XTRA_BEGIN marker to its SADHIP_XTRA_END
     for b in blocks:
-        is_x = bool(PK) and any(t.startswith("v_sad_u32") for t in b["ins"])
-        b["xtra"] = is_x
-    # the extra-candidate path = the run of blocks from the first to the last one containing v_sad_u32 (packed kernels)
-    xs = [i for i, b in enumerate(blocks) if b["xtra"]]
-    if xs:
-        for i in range(xs[0], xs[-1] + 1):
+        b["xtra"] = False
+    xb = [i for i, b in enumerate(blocks) if ";XB" in b["ins"]]
+    xe = [i for i, b in enumerate(blocks) if ";XE" in b["ins"]]
+    if xb and xe:
+        for i in range(xb[0], xe[-1] + 1):
             blocks[i]["xtra"] = True
     for b in blocks:
         (xtra_ins if b["xtra"] else main_ins).extend(b["ins"])
