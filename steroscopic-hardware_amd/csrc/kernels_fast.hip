@@ -870,7 +870,11 @@ struct Cw {                                         // P columns per lane: 4 (h 
       SADHIP_STAMP(0);
       if (out_row) {
         if constexpr (FL) reduce_row_fl(C, best);
-        else if (NEED_MASK && key_mask) reduce_row<2, 0>(C, M, best, (unsigned)dc, qn);
+        else if (NEED_MASK && key_mask) {                 // leftmost tiles only
+          asm volatile("; SADHIP_MASKED_BEGIN (tools/valu_budget.py: not on the common path)");
+          reduce_row<2, 0>(C, M, best, (unsigned)dc, qn);
+          asm volatile("; SADHIP_MASKED_END");
+        }
         else reduce_row<0, 0>(C, M, best, (unsigned)dc, qn);
       }
       if (xtra) {                                         // the odd candidate dx (wave-uniform branch)

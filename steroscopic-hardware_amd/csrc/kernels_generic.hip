@@ -123,11 +123,19 @@ hipError_t launch_mirror(const Job& j, int mode, hipStream_t s)
 {
   const int rw = j.x1 - j.x0, rh = j.y1 - j.y0;
   if (rw <= 0 || rh <= 0 || j.n <= 0) return hipSuccess;
-  dim3 grid((rw + 63) / 64, (rh + 3) / 4, j.n);
-  hipLaunchKernelGGL(k_disparity_mirror, grid, dim3(256), 0, s, j, mode);
-  const hipError_t e = hipGetLastError();
-  if (e == hipSuccess) note_launch(mode == 1 ? KIND_MIRROR_SADC : mode == 2 ? KIND_MIRROR_TESTPY : KIND_MIRROR_VERILOG);
-  return e;
+  for (int f0 = 0; f0 < j.n; f0 += 32768) {               // grid.z is limited to 65535
+    Job jj = j;
+    jj.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
+    jj.left += (size_t)f0 * j.left_frame_stride;
+    jj.right += (size_t)f0 * j.right_frame_stride;
+    jj.out += (size_t)f0 * j.out_frame_stride;
+    dim3 grid((rw + 63) / 64, (rh + 3) / 4, jj.n);
+    hipLaunchKernelGGL(k_disparity_mirror, grid, dim3(256), 0, s, jj, mode);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  note_launch(mode == 1 ? KIND_MIRROR_SADC : mode == 2 ? KIND_MIRROR_TESTPY : KIND_MIRROR_VERILOG);
+  return hipSuccess;
 }
 
 hipError_t launch_generic(const Job& j, hipStream_t s)

@@ -112,6 +112,9 @@ def analyse(lines):
         if "SADHIP_XTRA_BEGIN" in ln or "SADHIP_XTRA_END" in ln:
             ins.append(";" + ("XB" if "BEGIN" in ln else "XE"))       # markers the kernel emits around the extra-candidate path
             continue
+        if "SADHIP_MASKED_BEGIN" in ln or "SADHIP_MASKED_END" in ln:
+            ins.append(";" + ("MB" if "BEGIN" in ln else "ME"))       # ... and around the key-masking reduce of the leftmost tiles
+            continue
         if ln.startswith("\t") and not ln.lstrip().startswith((".", ";")):
             ins.append(ln.strip())
     best = None
@@ -173,10 +176,19 @@ def main():
     if xb and xe:
         for i in range(xb[0], xe[-1] + 1):
             blocks[i]["xtra"] = True
+    mb = [i for i, b in enumerate(blocks) if ";MB" in b["ins"]]
+    me = [i for i, b in enumerate(blocks) if ";ME" in b["ins"]]
+    masked_ins = []
     for b in blocks:
-        (xtra_ins if b["xtra"] else main_ins).extend(b["ins"])
+        b["masked"] = False
+    if mb and me:
+        for i in range(mb[0], me[-1] + 1):
+            blocks[i]["masked"] = True
+    for b in blocks:
+        (xtra_ins if b["xtra"] else masked_ins if b["masked"] else main_ins).extend(b["ins"])
     cnt, ops = summarise(main_ins)
     xcnt, _ = summarise(xtra_ins)
+    mcnt, _ = summarise(masked_ins)
     valu = cnt["fast"] + cnt["slow"] + cnt["qrate"]
     cyc = sum(cnt[k] * COST[k] for k in COST)
     slots = P * ND * (1 if not PK else 1)          # (column, candidate) pairs per lane per step = wave-wide slots of 64 candidates
@@ -187,6 +199,7 @@ def main():
         "row_loop_common_path": {"counts": cnt, "valu_instructions": valu, "ideal_simd_cycles": cyc,
                                  "cycles_per_valu_instruction": cyc / max(valu, 1)},
         "extra_candidate_path_one_wave_only": {"counts": xcnt, "ideal_simd_cycles": sum(xcnt[k] * COST[k] for k in COST)},
+        "masked_reduce_leftmost_tiles_only": {"counts": mcnt, "ideal_simd_cycles": sum(mcnt[k] * COST[k] for k in COST)},
         "slots_per_wave_step": slots,
         "valu_per_slot": valu / slots, "ideal_cycles_per_slot": cyc / slots,
         "mix_ceiling_Gwinst_per_s": 1024 * 2.4 / (cyc / max(valu + cnt["nop"], 1)),
@@ -197,13 +210,15 @@ def main():
     print(f"row loop, common path: {valu} VALU ({cnt['fast']} fast, {cnt['slow']} slow, {cnt['qrate']} quarter-rate) + {cnt['nop']} s_nop"
           f" + {cnt['other']} other; ideal {cyc} SIMD-cycles = {cyc / max(valu, 1):.2f} per VALU instruction")
     print(f"extra-candidate path (one wave per workgroup): {xcnt['fast']} fast, {xcnt['slow']} slow, {xcnt['nop']} s_nop, {xcnt['other']} other")
+    if masked_ins:
+        print(f"key-masking reduce (waves of the leftmost tile, instead of the plain reduce): {mcnt['fast']} fast, {mcnt['slow']} slow, {mcnt['nop']} s_nop")
     print(f"per slot of 64 candidates ({slots} slots per wave-step): {valu / slots:.2f} VALU, {cyc / slots:.2f} ideal SIMD-cycles")
     print(f"mix ceiling {res['mix_ceiling_Gwinst_per_s']:.1f} G wave-instructions/s; 2-cycle vector peak {res['vector_peak_2cycle_Gwinst_per_s']:.1f}")
     print("by opcode:", ", ".join(f"{k} x{v}" for k, v in list(res["by_opcode"].items())[:24]))
     if a.blocks:
         for b in blocks:
             c, _ = summarise(b["ins"])
-            print(f"  {b['label']:>12} {'xtra' if b['xtra'] else '    '} fast {c['fast']:4d} slow {c['slow']:4d} nop {c['nop']:3d} other {c['other']:4d}")
+            print(f"  {b['label']:>12} {'xtra' if b['xtra'] else 'mask' if b['masked'] else '    '} fast {c['fast']:4d} slow {c['slow']:4d} nop {c['nop']:3d} other {c['other']:4d}")
     if a.json:
         json.dump(res, open(a.json, "w"), indent=1)
     return res
