@@ -451,7 +451,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // (d <= x-h near the left image edge).  plan_for() gives these variants exact plans only (no chunk
   // runs past MaxDisparity); the extra candidate's empty high half is dropped here (qn = 1).
   // JOFS = index of the array's first candidate within the wave (0; ND for the extra candidate).
-  template <int MASK, int JOFS>
+  // LOW_ONLY = the register holds one real candidate (the extra one, low half): no key for the high half.
+  template <int MASK, int JOFS, bool LOW_ONLY = false>
   static __device__ __forceinline__ void stage_b(const Pre& r, int q, const unsigned long long (&M)[NM],
                                                  unsigned (&best)[P], unsigned dbase, int qn)
   {
@@ -502,6 +503,14 @@ struct Cw {                                         // P columns per lane: 4 (h 
     for (int p = 0; p < P; ++p) {
       if constexpr (PK) {
         unsigned ke = (s[p] << 16) | (dbase + 2 * q);             // v_lshl_or_b32
+        if constexpr (LOW_ONLY) {
+          if (MASK == 2) {
+            const int ie = JOFS + 2 * q - p + P - 1;
+            ke = sel_lanes(M[ie < NM ? ie : NM - 1], ke);
+          }
+          best[p] = ke < best[p] ? ke : best[p];
+          continue;
+        }
         unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
         if (MASK == 2) {
           const int ie = JOFS + 2 * q - p + P - 1, io = ie + 1;
@@ -580,7 +589,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
       Pre cur;
       stage_a(C, q, cur);
       __builtin_amdgcn_sched_barrier(0);
-      stage_b<MASK, JOFS>(cur, q, M, best, dbase, qn);
+      stage_b<MASK, JOFS, PK && W == 1>(cur, q, M, best, dbase, qn);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
