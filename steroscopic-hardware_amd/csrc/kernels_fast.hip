@@ -228,7 +228,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static constexpr int NC = PK ? ND / 2 : ND;       // accumulator registers per column
   static_assert(P == 4 || P == 8, "operand reads are whole ds_read_b128");
   static_assert(H >= 1 && H <= 2 * P - 1, "halo must fit in the two neighbour lanes on each side");
-  static_assert(H <= P || !PK, "two-lane halos exist for the unpacked variant only");
+  // two-lane halos (P < h): the unpacked variants, and packed P = 4 for h = 5..7 (see plan_count)
+  static_assert(H <= P || !PK || P == 4, "packed two-lane halos: P = 4 only");
   static_assert(ND % 4 == 0, "ND must keep every lane's R operands 16-byte aligned");
   static constexpr int TW = 64 * P;                 // columns per tile
   static constexpr int OL = P * ((H + P - 1) / P);  // first output column inside the tile
@@ -272,6 +273,23 @@ struct Cw {                                         // P columns per lane: 4 (h 
   static constexpr int MAXR = (TW + 4 * ND + 8 + 255) / 256;   // ... R elements per lane
   static constexpr bool NEED_MASK = PK && H > 5;    // packed h = 6, 7: 2*(2h+1)^2*255 does not fit u16
   static constexpr int NM = ND + P;                 // lane masks: one per (candidate - column), see run()
+  // Mask k is "lanes >= max(0, floor((T0 + k) / P))" for a wave-uniform T0: consecutive k share their
+  // mask P at a time, so a wave holds only NMB distinct masks plus one carry bit per residue k % P, and
+  // the mask of a compile-time k is a scalar select between two neighbours (SALU: no vector issue slot,
+  // no VGPR).  Round 2's first form kept all NM masks in SGPR pairs: 32-40 SGPRs, 13-25 of them parked
+  // in VGPR lanes by the compiler.
+  static constexpr int NMB = (NM - 1) / P + 2;
+  struct Masks {
+    unsigned long long mb[NMB];
+    unsigned carry;                                   // bit r: (r + T0 mod P) >= P
+    __device__ __forceinline__ unsigned long long at(int k) const
+    {
+      const int i = k / P;
+      unsigned long long a = mb[i], b = mb[i + 1];
+      asm volatile("" : "+s"(a), "+s"(b));            // two scalars selected HERE: not "mb[i + bit]" (array goes to scratch), not hoisted out of the row loop (40 SGPRs again)
+      return ((carry >> (k % P)) & 1u) ? b : a;
+    }
+  };
 
   // N ring pixels starting at a 16-byte aligned element -> one u32 register each.
   template <int N>
@@ -453,7 +471,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
   // JOFS = index of the array's first candidate within the wave (0; ND for the extra candidate).
   // LOW_ONLY = the register holds one real candidate (the extra one, low half): no key for the high half.
   template <int MASK, int JOFS, bool LOW_ONLY = false>
-  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const unsigned long long (&M)[NM],
+  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const Masks& M,
                                                  unsigned (&best)[P], unsigned dbase, int qn)
   {
     // window sum of column p = own columns + last (h-p) columns of the left lane + first (p+h-P+1)
@@ -481,9 +499,28 @@ struct Cw {                                         // P columns per lane: 4 (h 
       // DPP add one lane further.
       constexpr int N2 = H - P;                              // most columns needed from a lane two away
       unsigned t2l[N2 + 1], t2r[N2 + 1];
-      const unsigned tl = from_left(r.ps[P]), tr = from_right(r.ps[P]);
 #pragma unroll
       for (int k = 1; k <= N2; ++k) { t2l[k] = from_left(r.suf[k]); t2r[k] = from_right(r.ps[k]); }
+      if constexpr (2 * P - H - 1 <= 0) {
+        // h >= 2P-1 (P = 4, h = 7; P = 8, h = 15): every window holds BOTH neighbour lanes whole -- their
+        // totals join the lane's own once per candidate instead of once per column
+        unsigned u3 = r.ps[P] + from_left(r.ps[P]);
+        asm("" : "+v"(u3));
+        u3 += from_right(r.ps[P]);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int nl = H - p;
+          s[p] = nl > P ? u3 + from_left(t2l[nl - P]) : u3;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int nr = p + H - P + 1;
+          if (nr > P) s[p] += from_right(t2r[nr - P]);
+        }
+      } else {
+      const unsigned tl = from_left(r.ps[P]), tr = from_right(r.ps[P]);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int nl = H - p;                                // columns left of the lane (>= H-P+1 > 0)
@@ -498,6 +535,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
         if (nr >= P) { s[p] += tr; if (nr > P) s[p] += from_right(t2r[nr - P]); }
         else s[p] += from_right(r.ps[nr]);
       }
+      }
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -506,7 +544,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
         if constexpr (LOW_ONLY) {
           if (MASK == 2) {
             const int ie = JOFS + 2 * q - p + P - 1;
-            ke = sel_lanes(M[ie < NM ? ie : NM - 1], ke);
+            ke = sel_lanes(M.at(ie < NM ? ie : NM - 1), ke);
           }
           best[p] = ke < best[p] ? ke : best[p];
           continue;
@@ -514,8 +552,8 @@ struct Cw {                                         // P columns per lane: 4 (h 
         unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
         if (MASK == 2) {
           const int ie = JOFS + 2 * q - p + P - 1, io = ie + 1;
-          ke = sel_lanes(M[ie < NM ? ie : NM - 1], ke);
-          ko = (JOFS != 0 && 2 * q + 1 >= qn) ? KEY_INVALID : sel_lanes(M[io < NM ? io : NM - 1], ko);
+          ke = sel_lanes(M.at(ie < NM ? ie : NM - 1), ke);
+          ko = (JOFS != 0 && 2 * q + 1 >= qn) ? KEY_INVALID : sel_lanes(M.at(io < NM ? io : NM - 1), ko);
         }
         const unsigned m = ke < ko ? ke : ko;
         best[p] = m < best[p] ? m : best[p];                      // v_min3_u32
@@ -523,7 +561,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
         unsigned k = s[p];
         if (MASK == 2) {
           const int i = JOFS + q - p + P - 1;
-          k = sel_lanes(M[i < NM ? i : NM - 1], k);
+          k = sel_lanes(M.at(i < NM ? i : NM - 1), k);
         }
         best[p] = k < best[p] ? k : best[p];
       }
@@ -581,7 +619,7 @@ struct Cw {                                         // P columns per lane: 4 (h 
   }
 
   template <int MASK, int JOFS, int W>
-  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const unsigned long long (&M)[NM],
+  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const Masks& M,
                                                     unsigned (&best)[P], unsigned dbase, int qn)
   {
 #pragma unroll
@@ -778,18 +816,24 @@ struct Cw {                                         // P columns per lane: 4 (h 
     // per value of j - p, kept in SGPRs and applied with one v_cndmask_b32 per key.
     constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
     constexpr bool use_pen = !NEED_MASK;
-    // Lane masks, one 64-bit SGPR pair per value of j - p, held across the row loop.  They make these
-    // two kernel families (packed h = 6, 7) the only ones over the SGPR budget: the compiler parks
-    // 13-15 scalars in spare VGPR lanes (v_writelane / v_readlane; no scratch memory).  Measured
-    // alternatives: rebuilding each mask at its use from a one-SGPR lane
-    // threshold removes the spills and costs 8 % on config 5 (the leftmost tile's keys sit on the
-    // critical path); rebuilding all of them once per row step needs more SGPRs, not fewer.
-    unsigned long long M[NM];
+    // Lane masks (Masks above): NMB distinct 64-bit masks in SGPR pairs + the carry bits, held across the
+    // row loop; the mask of a key is a scalar select at its use.  (Measured alternatives, DESIGN.md
+    // section 6b: all ND + P masks ready-made cost 32-40 SGPRs, 13-25 of them parked in VGPR lanes; a
+    // vector compare per key instead of a mask costs 8 % on config 5.)
+    Masks M;
+    {
+      const int T0 = dc + H - tx;                         // mask k: lanes >= max(0, floor((T0 + k) / P))
+      const int q0 = T0 >= 0 ? T0 / P : -((-T0 + P - 1) / P);
+      const int c = T0 - q0 * P;                          // 0 .. P-1
 #pragma unroll
-    for (int k = 0; k < NM; ++k) {
-      const int t = dc + H - tx + (k - (P - 1)) + P - 1;  // ceil(num / P) = floor((num + P-1) / P)
-      const int l0 = t > 0 ? t / P : 0;
-      M[k] = (NEED_MASK && l0 < 64) ? (~0ull << l0) : 0ull;
+      for (int i = 0; i < NMB; ++i) {
+        const int l0 = q0 + i > 0 ? q0 + i : 0;
+        M.mb[i] = (NEED_MASK && l0 < 64) ? (~0ull << l0) : 0ull;
+      }
+      M.carry = 0u;
+#pragma unroll
+      for (int r = 0; r < P; ++r) M.carry |= (r + c >= P) ? (1u << r) : 0u;
+      M.carry = (unsigned)__builtin_amdgcn_readfirstlane((int)M.carry);
     }
     // Candidates d > D (a chunk that runs past MaxDisparity) exist for no pixel: same trick with the
     // class c == w-1 (mod 2h+1), 0 <= c < w, which every window has exactly once -- also the windows
@@ -961,7 +1005,7 @@ int env_int(const char* name, int dflt)
     static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
-                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS"};
+                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -984,15 +1028,29 @@ constexpr int env_int(const char*, int dflt) { return dflt; }
 // its most loaded SIMD, i.e. ceil(NW/4) waves of (per-candidate work * ND + per-wave overhead) per
 // row.  exact: no chunk may run past the last candidate (packed h = 6, 7 masks keys with lane masks
 // that cannot express it).
-//   packed   (h <= 7): P = 4 (h <= 4), ND in {4, 8, 12, 16, 20, 24};  P = 8 (h = 5..7), ND in {4, 8, 12}
+//   packed   (h <= 7): P = 4, ND in {4, 8, 12, 16} (h <= 4 also 20, 24; h = 5..7 with two-lane halos);
+//                      P = 8 (h = 5..7, when P = 4 has no plan: exact plans of the lane-mask variants), ND in {4, 8, 12}
 //   unpacked (h = 8; h = 6, 7 without an exact packed plan; SADHIP_TUNE_PK=0): P = 8, ND in {4, 8, 12}
+// Measured on MI355X: for h = 5..7 the P = 4 kernels -- 4..8 waves per workgroup, two to four
+// independent workgroups per CU -- beat the P = 8 ones (8..16 waves, one or two per CU) by 2-15 % although
+// their windows span five lanes instead of three (7.0 against 6.6 instructions per 64 candidates).
+static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int p);
+
 Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
+{
+  const int force_p = env_int("SADHIP_TUNE_P", 0);              // tuning aid: force the columns per lane
+  if (pk && h <= 7 && force_p != 8) {
+    const Plan pl = plan_count_p(h, pk, count, exact, maxdisp, 4);
+    if (pl.nw || force_p == 4 || h <= 4) return pl;
+  }
+  return plan_count_p(h, pk, count, exact, maxdisp, 8);
+}
+
+static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int p)
 {
   Plan best{0, 0, 0, false, false, false};
   const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aids: force a chunk size / wave count
   const int force_nw = env_int("SADHIP_TUNE_NW", 0);
-  int p = (h <= 4 && pk) ? 4 : 8;
-  if (env_int("SADHIP_TUNE_P", 0) == 8) p = 8;                  // tuning aid: 8 columns per lane for h <= 4 too
   long best_cost = 1L << 60;
   // chunk sizes: P = 4 up to 24; P = 8 up to 12 for the penalty variants (packed h = 5), 8 otherwise --
   // measured: the lane-mask variants spill at ND 12 (B15 D48: 47 vs 36 us) and the unpacked ones
@@ -1003,6 +1061,7 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
     for (int nw = 4; nw <= 16; ++nw) {                          // (two-wave workgroups for D <= 48 measured 25-35 % slower)
       if (force_nw && force_nw != nw) continue;
       if (p == 4 && nw > 8) continue;                           // measured: 11-16 waves (one workgroup per CU) lose ~10 % to passes of 8 waves
+      if (p == 4 && h > 4 && nd > 16) continue;                 // two-lane halo kernels exist for ND 4, 8, 12, 16
       if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
       // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated
       // for packed h = 7 and unpacked h = 8, chunk size 8, <= 8 waves; unpacked pixels << bitlen(D) must fit)
@@ -1088,6 +1147,65 @@ std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
   return passes;
 }
 
+// ---- strip count of a launch ---------------------------------------------------------------------
+// base = workgroups per strip layer (tiles x frames), rows = output rows, h2 = 2h warm-up rows per strip,
+// cus = compute units, per_cu = workgroups of this kernel a CU holds.  Cost of ns strips of th rows:
+//   work per workgroup  = th + h2 + 4 rows (4: set-up, ring fill, first barrier)
+//   k = ceil(base*ns / cus) workgroups on the busiest CU (round-robin dispatch)
+//   k <= per_cu: one round; a workgroup with fewer neighbours runs faster -- measured single 1080p pairs:
+//                1 / 2 / 5 resident workgroups take 0.42 / 0.55 / 1.0 of the full-occupancy time per row
+//                -> duration factor 0.27 + 0.73 * k / per_cu
+//   k >  per_cu: between base*ns / (cus*per_cu) rounds (perfect balance) and ceil(k / per_cu) (the busiest CU): their mean
+//   + 0.15 of a workgroup's duration for the tail in both cases: workgroups are not equally long (the
+//   leftmost tiles mask keys, CUs differ), and the longer they are the longer the chip waits for the last
+//   one (measured: 128 1080p pairs as 1 / 4 strips 27.7 / 24.2 us per pair; config 5 with 16 pairs as
+//   1 / 2 / 4 / 6 rounds 228 / 218 / 213 / 210)
+static long choose_strips(long base, long rows, int h2, int cus, int per_cu)
+{
+  const long max_strips = std::max<long>(1, (rows + 15) / 16);
+  const double slots = (double)cus * per_cu;
+  double best = 1e300;
+  long best_ns = 1;
+  for (long ns = 1; ns <= max_strips; ++ns) {
+    const long th = (rows + ns - 1) / ns;
+    if ((rows + th - 1) / th != ns) continue;                   // this strip height gives fewer strips: counted there
+    const long w = base * ns, k = (w + cus - 1) / cus;
+    const double whole = (double)((k + per_cu - 1) / per_cu);   // rounds on the busiest CU
+    const double t = (k <= per_cu ? 0.27 + 0.73 * (double)k / per_cu : 0.5 * ((double)w / slots + whole)) + 0.15;
+    const double cost = t * (double)(th + h2 + 4);
+    if (cost < best * 0.999) { best = cost; best_ns = ns; }     // ties: fewer strips
+  }
+  return best_ns;
+}
+
+static int cu_count()
+{
+  thread_local int dev_cached = -1, cus = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return cus;
+  if (dev != dev_cached) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    dev_cached = dev;
+  }
+  return cus;
+}
+
+template <typename Kernel>
+static int wgs_per_cu(Kernel kernel, int threads, size_t lds)
+{
+  struct Entry { int dev, threads; size_t lds; int n; };
+  thread_local std::vector<Entry> cache;                        // per kernel instantiation (template) and thread
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  for (const Entry& e : cache)
+    if (e.dev == dev && e.threads == threads && e.lds == lds) return e.n;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+  cache.push_back(Entry{dev, threads, lds, n});
+  return n;
+}
+
 // dry: run every host-side check (instantiation exists, per-wave shares fit, LDS fits) and return
 // without launching -- what fast_supported() asks, so that a job the column-wave kernel cannot run
 // is routed to the generic kernel at PLANNING time and never by a silent fallback after a failure.
@@ -1126,30 +1244,36 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   const int ntiles = k1 - k0 + 1;
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
-  // strip height.  Each strip repeats 2h warm-up rows, so strips should be tall; but the chip must
-  // be filled (small batches: split until ~512 workgroups exist), and a launch of few very long
-  // workgroups balances badly across CUs (128 pairs at 1080p: 1 strip 27.7 us/pair, 4 strips
-  // 24.2): when the batch alone fills the chip, cut strips down to ~48h rows (warm-up <= 4 %) while
-  // the grid stays <= ~4096 workgroups.
+  static_assert(K::NR == 2 * H + 3 && K::NB == 2 && K::RBW == 72 * P && K::XOFF == ((W16 || K::SWZ) ? 7 : 3), "plan_lds_bytes mirrors Cw");
+  Plan plk = pl; plk.p = P; plk.nd = ND; plk.pk = PK; plk.w16 = W16; plk.fl = FL;
+  const size_t lds = plan_lds_bytes(plk, H, j.maxdisp) + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
+  if (lds > 160 * 1024 || lds < (size_t)(K::NR + 1) * (K::TW + RW) * sizeof(typename K::Px)) return hipErrorInvalidValue;
+  if (dry) return hipSuccess;
+  // Strips per frame.  Each strip repeats 2h warm-up rows (+ set-up), so strips should be tall; but the
+  // chip must be filled, a launch that is a little more than one round of workgroups waits for its tail,
+  // and many short workgroups balance better than few long ones (leftmost tiles mask keys, CUs differ).
+  // choose_strips() minimises a small cost model over the possible strip counts, with the number of
+  // workgroups of THIS kernel a CU holds asked from the runtime (registers, LDS, waves).
   const long base = (long)ntiles * j.n;
-  // Small batches (the WebUI's case: one pair per call): a strip costs 2h warm-up rows, a second workgroup on
-  // a CU slows the first.  Measured single 1080p pairs: B9 (P = 4, five 4-wave workgroups fit a CU) 64.8 /
-  // 53.4 / 67.7 us at 256 / 512 / 768 workgroups; B16 (P = 8, two 8-wave workgroups fit) 82.8 / 123.2 / 117.6.
-  const long want = env_int("SADHIP_TUNE_WGS", P == 4 ? 512 : 256);
-  const long rows_target = env_int("SADHIP_TUNE_ROWS", 48 * H), wg_max = env_int("SADHIP_TUNE_WGMAX", 4096);
-  long nstrips = (want + base - 1) / base;
-  if (base >= want) nstrips = std::max<long>(1, std::min<long>(rows / rows_target, wg_max / base));
+  long nstrips;
+  if (env_int("SADHIP_TUNE_LEGACY_STRIPS", 0)) {                // round 2's constants, for comparison
+    const long want = env_int("SADHIP_TUNE_WGS", P == 4 ? 512 : 256);
+    const long rows_target = env_int("SADHIP_TUNE_ROWS", 48 * H), wg_max = env_int("SADHIP_TUNE_WGMAX", 4096);
+    nstrips = (want + base - 1) / base;
+    if (base >= want) nstrips = std::max<long>(1, std::min<long>(rows / rows_target, wg_max / base));
+  } else if (env_int("SADHIP_TUNE_STRIPS", 0) > 0) {
+    nstrips = env_int("SADHIP_TUNE_STRIPS", 0);
+  } else {
+    nstrips = choose_strips(base, rows, 2 * H, cu_count(), wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL>, 64 * pl.nw, lds));
+  }
   const long max_strips = (rows + 15) / 16;
   if (nstrips > max_strips) nstrips = max_strips;
   if (nstrips < 1) nstrips = 1;
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
-  static_assert(K::NR == 2 * H + 3 && K::NB == 2 && K::RBW == 72 * P && K::XOFF == ((W16 || K::SWZ) ? 7 : 3), "plan_lds_bytes mirrors Cw");
-  Plan plk = pl; plk.p = P; plk.nd = ND; plk.pk = PK; plk.w16 = W16; plk.fl = FL;
-  const size_t lds = plan_lds_bytes(plk, H, j.maxdisp) + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
-  if (lds < (size_t)(K::NR + 1) * (K::TW + RW) * sizeof(typename K::Px)) return hipErrorInvalidValue;   // (cannot happen: same formula)
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (dry) return hipSuccess;
+  if (env_int("SADHIP_TUNE_VERBOSE", 0))
+    fprintf(stderr, "sadhip: P%d ND%d H%d nw%d: %ld strips of %d rows x %ld workgroups per layer, %d per CU, lds %zu\n", P, ND, H, pl.nw, nstrips, a.th,
+            base, wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL>, 64 * pl.nw, lds), lds);
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     CwArgs aa = a;
     aa.j.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
@@ -1246,6 +1370,7 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   if (pl.p == 8 && pl.nd == 8 && h == 7 && pl.pk) return launch_t<8, 8, 7, true>(j, pl, io, s, dry);
   if (pl.p == 8 && pl.nd == 8 && h == 5 && !pl.pk) return launch_t<8, 8, 5, false, 1024>(j, pl, io, s, dry);
   if (pl.p == 4 && pl.nd == 16 && h == 4 && pl.pk) return launch_t<4, 16, 4, true>(j, pl, io, s, dry);
+  if (pl.p == 4 && pl.nd == 16 && h == 7 && pl.pk) return launch_t<4, 16, 7, true>(j, pl, io, s, dry);
   return hipErrorInvalidValue;
 #else
   if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry);
@@ -1258,7 +1383,12 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
 #define SADHIP_P8(NDD) SADHIP_CASE(8, NDD, 5, true); SADHIP_CASE(8, NDD, 6, true); SADHIP_CASE(8, NDD, 7, true)
   SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
   SADHIP_P8(4); SADHIP_P8(8); SADHIP_CASE(8, 12, 5, true);
+  // packed P = 4 with two-lane halos (h = 5..7): wide disparity ranges as 8-wave workgroups, two or three per CU
+#define SADHIP_P4H(NDD) SADHIP_CASE(4, NDD, 5, true); SADHIP_CASE(4, NDD, 6, true); SADHIP_CASE(4, NDD, 7, true)
+  SADHIP_P4H(4); SADHIP_P4H(8); SADHIP_P4H(12); SADHIP_P4H(16);
+#ifdef SADHIP_TUNING
   SADHIP_CASE(8, 8, 4, true); SADHIP_CASE(8, 12, 4, true);     // forced for comparison (SADHIP_TUNE_P=8)
+#endif
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
 #define SADHIP_U(HH, NDD) \
   if (pl.p == 8 && pl.nd == NDD && h == HH && !pl.pk) \

@@ -78,9 +78,9 @@ def test_no_column_wave_kernel_spills():
     """hipcc -Rpass-analysis=kernel-resource-usage over kernels_fast.hip (make remarks): NO instantiation
     may use scratch memory or spill a VGPR (round 1: the kernels the reference's default parameters 16/64
     select spilled 14-21 VGPRs, 60-88 bytes of scratch per lane).  SGPR -> VGPR-lane parking (no memory
-    traffic) is tolerated only in the two lane-mask families (packed h = 6, 7: 16 64-bit masks live across
-    the row loop), bounded; everything else reports 0 there too.  DESIGN.md section 6b has the measured
-    alternatives."""
+    traffic) is tolerated only in the lane-mask families (packed h = 6, 7: up to 7 64-bit masks live across
+    the row loop on top of a kernel that already uses ~100 SGPRs), bounded at 12 (round 2 started at 13-25);
+    everything else reports 0 there too.  DESIGN.md section 6b has the measured alternatives."""
     import subprocess
     csrc = os.path.join(REPO, "steroscopic-hardware_amd", "csrc")
     rem = os.path.join(REPO, "steroscopic-hardware_amd", "lib", "kernels_fast.remarks")
@@ -96,7 +96,7 @@ def test_no_column_wave_kernel_spills():
         sc, ss, vs = val(r"ScratchSize \[bytes/lane\]"), val("SGPRs Spill"), val("VGPRs Spill")
         m = re.search(r"k_colwaveILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", name)
         lane_mask_family = bool(m) and m.group(4) == "1" and m.group(3) in ("6", "7")
-        if sc or vs or (ss and not lane_mask_family) or ss > 16:
+        if sc or vs or (ss and not lane_mask_family) or ss > 12:
             bad.append((name, sc, ss, vs))
     assert not bad, bad
 
@@ -171,7 +171,7 @@ def test_whole_ui_parameter_grid_plans_on_the_fast_kernel():
 def test_planner_invariants_over_the_parameter_space():
     """plan_job (kernels_fast.hip) through sadhip_plan_describe: passes tile [0, D] without gaps, stay
     inside the launch limits the kernel assumes, and keep the properties the kernel relies on."""
-    seen = set()
+    seen, p4_first = set(), set()
     for block in range(2, 32):
         hh = block // 2
         for maxdisp in list(range(1, 70)) + [95, 96, 100, 127, 128, 129, 160, 192, 193, 200, 255, 256, 257, 300, 511, 512, 1000, 4096]:
@@ -190,7 +190,10 @@ def test_planner_invariants_over_the_parameter_space():
                 if i + 1 < len(plan):
                     assert slots == ps["count"] and ps["extra"] == 0       # full passes are exact
                 if ps["packed"]:
-                    assert hh <= 7 and ps["p"] == (4 if hh <= 4 else 8)
+                    assert hh <= 7 and (ps["p"] == 4 or hh >= 5)            # P = 8 packed: only where P = 4 has no plan
+                    if ps["p"] == 4:
+                        assert ps["nw"] <= 8 and (hh <= 4 or ps["nd"] <= 16)    # two-lane halo kernels: ND 4..16
+                    p4_first.add((hh, ps["p"]))
                     if hh > 5:
                         assert slots + ps["extra"] == ps["count"]           # lane-mask variants: exact plans only
                 else:
@@ -200,7 +203,11 @@ def test_planner_invariants_over_the_parameter_space():
                     assert ps["p"] == 8 and ps["nd"] == 8 and ps["nw"] <= 8 and (ps["packed"] or maxdisp <= 255)
                 seen.add((ps["p"], ps["nd"], ps["packed"], ps["w16"]))
             assert at in (0, maxdisp + 1)
-    assert {(4, 16, 1, 0), (8, 8, 1, 1), (8, 8, 0, 1), (8, 12, 1, 0), (8, 4, 0, 0)} <= seen
+    assert {(4, 16, 1, 0), (8, 8, 0, 1), (8, 4, 0, 0)} <= seen
+    assert {(5, 4), (6, 4), (7, 4)} <= p4_first                 # h = 5..7 run the P = 4 kernels ...
+    for block, maxdisp in ((15, 128), (15, 64), (13, 96), (11, 128), (11, 16)):
+        assert [ps["p"] for ps in capi.plan_describe(1920, 1080, block, maxdisp)] == [4]
+    assert (7, 8) in p4_first or (6, 8) in p4_first             # ... and fall back to P = 8 for a D without an exact P = 4 plan
     assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0, fl=0,
                                                          lds=capi.plan_describe(1920, 1080, 9, 64)[0]["lds"])]
 

@@ -12,8 +12,8 @@ __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
   using K = Cw<P, ND, H, PK>;
   constexpr int NC = K::NC;
   extern __shared__ __attribute__((aligned(16))) unsigned smem[];
-  unsigned C[P][NC]; unsigned long long M[K::NM]; unsigned best[P];
-  for (int k = 0; k < K::NM; ++k) M[k] = ~0ull;
+  unsigned C[P][NC]; typename K::Masks M; unsigned best[P];
+  for (int k = 0; k < K::NMB; ++k) M.mb[k] = ~0ull; M.carry = 0u;
   for (int p = 0; p < P; ++p) { best[p] = 0xffffffffu; for (int q = 0; q < NC; ++q) C[p][q] = io[(threadIdx.x * P + p) * NC + q] & 0xff00ff; }
   for (int i = threadIdx.x; i < 8192; i += blockDim.x) smem[i] = io[i] & 0xff;
   __syncthreads();
