@@ -213,7 +213,7 @@ __device__ __forceinline__ void wg_barrier()
 }
 
 template <int P, int ND, int H, bool PK, bool W16 = false, bool FL = false>
-struct Cw {                                         // P columns per lane: 4 (h <= 4) or 8 (h <= 15)
+struct Cw {                                         // P columns per lane: 4 (packed, h <= 7; two-lane halos from h = 5) or 8 (h <= 15)
   // FL: "fast-run float" variant of the unpacked layout (P = 8, ND = 8, h = 4..7).  Measured on MI355X
   // (tools/ubench/valu_mix.hip, valu_rates2.hip): a fast-class instruction (v_add/v_sub_f32, also
   // with a |x| source modifier) costs ~2.3 SIMD-cycles only inside a RUN of fast-class instructions;
