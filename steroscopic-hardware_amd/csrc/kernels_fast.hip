@@ -84,6 +84,9 @@ struct CwArgs {
 };
 
 constexpr unsigned KEY_INVALID = 0xffffffffu;
+// Compile-time switches that rebuild two measured alternatives, never set by the Makefile:
+//   -DSADHIP_X_BUFLOAD   raw buffer loads for the unpacked variants' row fetch too (slower: register allocation)
+//   -DSADHIP_X_NORECOMP  row-share state held across the row loop instead of re-derived per step (spills)
 #ifdef SADHIP_X_BUFLOAD
 constexpr bool X_BUFLOAD = true;
 #else
