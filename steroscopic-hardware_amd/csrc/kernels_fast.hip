@@ -1008,7 +1008,7 @@ int env_int(const char* name, int dflt)
     static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
-                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS"};
+                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -1163,9 +1163,9 @@ std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
 //   leftmost tiles mask keys, CUs differ), and the longer they are the longer the chip waits for the last
 //   one (measured: 128 1080p pairs as 1 / 4 strips 27.7 / 24.2 us per pair; config 5 with 16 pairs as
 //   1 / 2 / 4 / 6 rounds 228 / 218 / 213 / 210)
-static long choose_strips(long base, long rows, int h2, int cus, int per_cu)
+static long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_rows)
 {
-  const long max_strips = std::max<long>(1, (rows + 15) / 16);
+  const long max_strips = std::max<long>(1, (rows + min_rows - 1) / min_rows);
   const double slots = (double)cus * per_cu;
   double best = 1e300;
   long best_ns = 1;
@@ -1258,6 +1258,8 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   // choose_strips() minimises a small cost model over the possible strip counts, with the number of
   // workgroups of THIS kernel a CU holds asked from the runtime (registers, LDS, waves).
   const long base = (long)ntiles * j.n;
+  // shortest strip: 8 rows (single small frames: 640x480 28.8 -> 26.7 us, 1280x720 B9 47.1 -> 38.5; no change at 1080p)
+  const int min_rows = env_int("SADHIP_TUNE_MINROWS", 8);
   long nstrips;
   if (env_int("SADHIP_TUNE_LEGACY_STRIPS", 0)) {                // round 2's constants, for comparison
     const long want = env_int("SADHIP_TUNE_WGS", P == 4 ? 512 : 256);
@@ -1267,9 +1269,9 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   } else if (env_int("SADHIP_TUNE_STRIPS", 0) > 0) {
     nstrips = env_int("SADHIP_TUNE_STRIPS", 0);
   } else {
-    nstrips = choose_strips(base, rows, 2 * H, cu_count(), wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL>, 64 * pl.nw, lds));
+    nstrips = choose_strips(base, rows, 2 * H, cu_count(), wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL>, 64 * pl.nw, lds), min_rows);
   }
-  const long max_strips = (rows + 15) / 16;
+  const long max_strips = (rows + min_rows - 1) / min_rows;
   if (nstrips > max_strips) nstrips = max_strips;
   if (nstrips < 1) nstrips = 1;
   a.th = (int)((rows + nstrips - 1) / nstrips);
