@@ -7,7 +7,7 @@
 
 Workload (BASELINE.json configs[2]/[3]): 1920x1080 synthetic grayscale pairs, block 9, Dmax 64.
 A "step" = one pass of the hot path over this rank's shard of the frame stream: F independent
-pairs (default 128 = 1024 / 8, config 4's per-GPU share), device-resident (generated in HBM
+pairs (default 1024 = the length of config 4's frame stream, per GPU), device-resident (generated in HBM
 before the timed region), one batched launch on torch's current stream through the C ABI.
 Frames shard round-robin across ranks with no data-path collective (weak scaling); the two
 parameters are broadcast from rank 0 over RCCL.
@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-gpu", type=int, default=128)
+    ap.add_argument("--frames-per-gpu", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU baseline (default: every core this process may use)")
     ap.add_argument("--flags", type=int, default=0, help="sadhip flags (2 = force generic kernel)")
@@ -210,7 +210,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": None,
                      "kernel_avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                     "note": "path is integer-VALU bound (SURVEY 8d); see gcand_per_s and DESIGN.md"},
+                     "note": "path is integer-VALU bound (SURVEY 8d); see gcand_per_s and DESIGN.md. A step at BlockSize 9 is two "
+                             "kernels on one stream (triple-column form for the tiles left of the image's last two columns, plain "
+                             "form for the last tile); kernel_avg_launch_ms spans both"},
     }
 
     ran = sha.capi.last_kernel_kind()                             # what the timed launches really ran (no silent fallback)

@@ -140,6 +140,27 @@ __device__ __forceinline__ void sad_sub4x(unsigned& c0, unsigned& c1, unsigned& 
       : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
       : "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
 }
+// Byte-lane forms of the two helpers above (triple-column operands, Cw::TR3: three pixel bytes per word).
+__device__ __forceinline__ void sad8_acc(unsigned& acc, unsigned a, unsigned b)
+{
+  asm("v_sad_u8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void sad8_sub4x(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
+                                           unsigned l0, unsigned l1, unsigned l2, unsigned l3,
+                                           unsigned r0, unsigned r1, unsigned r2, unsigned r3)
+{
+  unsigned t0, t1, t2, t3;
+  asm("v_sad_u8 %4, %8, %12, 0\n\t"
+      "v_sad_u8 %5, %9, %13, 0\n\t"
+      "v_sad_u8 %6, %10, %14, 0\n\t"
+      "v_sad_u8 %7, %11, %15, 0\n\t"
+      "v_sub_u32 %0, %0, %4\n\t"
+      "v_sub_u32 %1, %1, %5\n\t"
+      "v_sub_u32 %2, %2, %6\n\t"
+      "v_sub_u32 %3, %3, %7"
+      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
+}
 // ---- packed variant: one register holds the column sums of two adjacent disparities as u16 halves.
 // Pixels in LDS are plain zero-extended bytes, so v_sad_u8 / v_sad_hi_u8 (|a-b| over 4 byte lanes,
 // result added to the low / high half of the accumulator) are exact single-pixel differences.
@@ -215,7 +236,7 @@ __device__ __forceinline__ void wg_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int P, int ND, int H, bool PK, bool W16 = false, bool FL = false>
+template <int P, int ND, int H, bool PK, bool W16 = false, bool FL = false, bool TR = false>
 struct Cw {                                         // P columns per lane: 4 (packed, h <= 7; two-lane halos from h = 5) or 8 (h <= 15)
   // FL: "fast-run float" variant of the unpacked layout (P = 8, ND = 8, h = 4..7).  Measured on MI355X
   // (tools/ubench/valu_mix.hip, valu_rates2.hip): a fast-class instruction (v_add/v_sub_f32, also
@@ -275,6 +296,23 @@ struct Cw {                                         // P columns per lane: 4 (pa
   struct Src { const Px* a; const Px* b; };           // operand block of a lane: even quads at a, odd quads at b (SWZ); else all at a
   static constexpr int MAXR = (TW + 4 * ND + 8 + 255) / 256;   // ... R elements per lane
   static constexpr bool NEED_MASK = PK && H > 5;    // packed h = 6, 7: 2*(2h+1)^2*255 does not fit u16
+  // TR3: "triple-column" form of the packed P = 4 variants whose window width is a multiple of three
+  // (BlockSize 9: h = 4, and BlockSize 3: h = 1).  v_sad_u8 sums FOUR byte lanes, and the plain form
+  // uses one of them.  Here a ring word of column c holds the pixels c, c+1, c+2 as its three low
+  // bytes, so the same instruction accumulates T(x, d) = the column sums of x, x+1, x+2 together, and
+  // the (2h+1)-wide window of pixel x is T(x-h) + T(x-h+3) + ... : for h = 4 two additions per column
+  // (seven of eight as DPP adds pulling from a neighbour lane) instead of the prefix sums + suffix
+  // differences + two DPP adds of the plain form -- 8 instructions per register instead of 13; for
+  // h = 1 the window IS T(x-1).  Same sums, same keys, same penalties per window (init_sum below).
+  // At the right image edge the form is wrong: the register of column w-2 (w-1) would also sum |0 - R| of
+  // the columns w (w, w+1), which a clipped window of the reference does not contain -- R(x-d) is a real
+  // pixel there, only L is outside the image.  (At the left edge both are outside: |0 - 0|.)  So a
+  // workgroup whose tile holds the columns w-2, w-1 runs the plain form (k_colwave picks per tile);
+  // TR is set for the other tiles of the BlockSize-9 kernels only.  (BlockSize 3, whose window IS one
+  // triple, measured slower in this form: two more byte loads per streamed pixel for no arithmetic saved
+  // that its small horizontal pass had not saved already.)
+  static constexpr bool TR3 = TR;
+  static_assert(!TR || (PK && P == 4 && !W16 && !FL && H == 4), "triple-column form: packed P = 4, h = 4");
   static constexpr int NM = ND + P;                 // lane masks: one per (candidate - column), see run()
   // Mask k is "lanes >= max(0, floor((T0 + k) / P))" for a wave-uniform T0: consecutive k share their
   // mask P at a time, so a wave holds only NMB distinct masks plus one carry bit per residue k % P, and
@@ -430,7 +468,10 @@ struct Cw {                                         // P columns per lane: 4 (pa
       load_px(lin, li);
       load_px(rxin, ri);
 #pragma unroll
-      for (int p = 0; p < P; ++p) sad_acc(CX[p][0], li[p], ri[p + XOFF]);
+      for (int p = 0; p < P; ++p) {
+        if constexpr (TR3) sad8_acc(CX[p][0], li[p], ri[p + XOFF]);
+        else sad_acc(CX[p][0], li[p], ri[p + XOFF]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -438,9 +479,14 @@ struct Cw {                                         // P columns per lane: 4 (pa
       load_px(lout, lo);
       load_px(rxout, ro);
 #pragma unroll
-      for (int p = 0; p < P; p += 4)
-        sad_sub4x(CX[p][0], CX[p + 1][0], CX[p + 2][0], CX[p + 3][0], lo[p], lo[p + 1], lo[p + 2], lo[p + 3],
-                  ro[p + XOFF], ro[p + XOFF + 1], ro[p + XOFF + 2], ro[p + XOFF + 3]);
+      for (int p = 0; p < P; p += 4) {
+        if constexpr (TR3)
+          sad8_sub4x(CX[p][0], CX[p + 1][0], CX[p + 2][0], CX[p + 3][0], lo[p], lo[p + 1], lo[p + 2], lo[p + 3],
+                     ro[p + XOFF], ro[p + XOFF + 1], ro[p + XOFF + 2], ro[p + XOFF + 3]);
+        else
+          sad_sub4x(CX[p][0], CX[p + 1][0], CX[p + 2][0], CX[p + 3][0], lo[p], lo[p + 1], lo[p + 2], lo[p + 3],
+                    ro[p + XOFF], ro[p + XOFF + 1], ro[p + XOFF + 2], ro[p + XOFF + 3]);
+      }
     }
   }
 
@@ -458,6 +504,11 @@ struct Cw {                                         // P columns per lane: 4 (pa
   static __device__ __forceinline__ void stage_a(const unsigned (&C)[P][W], int q, Pre& r)
   {
     r.ps[0] = 0;
+    if constexpr (TR3) {                                   // no prefix sums: ps[k + 1] carries the triple sum T of column k as it is
+#pragma unroll
+      for (int k = 0; k < P; ++k) r.ps[k + 1] = C[k][q];
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < P; ++k) r.ps[k + 1] = r.ps[k] + C[k][q];
 #pragma unroll
@@ -482,7 +533,35 @@ struct Cw {                                         // P columns per lane: 4 (pa
     // then all "right" pulls): a DPP instruction that reads a VGPR written by the instruction just
     // before it costs wait states, so the two adds of one column are kept P instructions apart.
     unsigned s[P];
-    if constexpr (H <= P) {
+    if constexpr (TR3) {
+      // window of column p = T(p-h) + T(p-h+3) + ... ((2h+1)/3 terms); T(i) of this lane for 0 <= i < P, of the
+      // left lane for i < 0 (T(i+P) there), of the right lane for i >= P.  Own-lane terms first, then the
+      // left pulls, then (second sweep, as in the plain form) the right pulls: every pull is one DPP add.
+      constexpr int M3 = (2 * H + 1) / 3;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        bool have = false;
+#pragma unroll
+        for (int j = 0; j < M3; ++j) {
+          const int i = p - H + 3 * j;
+          if (i >= 0 && i < P) { s[p] = have ? s[p] + r.ps[i + 1] : r.ps[i + 1]; have = true; }
+        }
+#pragma unroll
+        for (int j = 0; j < M3; ++j) {
+          const int i = p - H + 3 * j;
+          if (i < 0) { s[p] = have ? s[p] + from_left(r.ps[i + P + 1]) : from_left(r.ps[i + P + 1]); have = true; }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int j = 0; j < M3; ++j) {
+          const int i = p - H + 3 * j;
+          if (i >= P) s[p] += from_right(r.ps[i - P + 1]);
+        }
+    } else if constexpr (H <= P) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int a = p - H, b = p + H;
@@ -684,6 +763,12 @@ struct Cw {                                         // P columns per lane: 4 (pa
         unsigned v = 0u;
         if (yy >= 0 && yy < j.h && col >= 0 && col < j.w)
           v = (unsigned)(isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride)[col];
+        if constexpr (TR3) {                                 // + the two pixels to the right in bytes 1 and 2
+#pragma unroll
+          for (int k = 1; k < 3; ++k)
+            if (yy >= 0 && yy < j.h && col + k >= 0 && col + k < j.w)
+              v |= (unsigned)(isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride)[col + k] << (8 * k);
+        }
         ring[i] = (Px)(FL ? __float_as_uint((float)v) : v << a.pixshift);
       }
     }
@@ -727,6 +812,17 @@ struct Cw {                                         // P columns per lane: 4 (pa
     for (int v = 0; v < MAXL; ++v) mineL[v] = __builtin_amdgcn_ballot_w64(lane + 64 * v < a.shl && il0 + 64 * v < TW);
 #pragma unroll
     for (int v = 0; v < MAXR; ++v) mineR[v] = __builtin_amdgcn_ballot_w64(lane + 64 * v < a.shr && ir0 + 64 * v < RW);
+    // TR3: a pixel triple is one unaligned dword load where all three columns (and the byte after them) are
+    // inside the row for every position this wave streams; waves that touch the row's ends load bytes.
+    bool whole_words = false;
+    if constexpr (TR3) {
+      bool ok = true;
+#pragma unroll
+      for (int v = 0; v < MAXL; ++v) ok = ok && (lcol[v] == NOT_MINE || (lcol[v] >= 0 && lcol[v] <= j.w - 4));
+#pragma unroll
+      for (int v = 0; v < MAXR; ++v) ok = ok && (rcol[v] == NOT_MINE || (rcol[v] >= 0 && rcol[v] <= j.w - 4));
+      whole_words = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+    }
     auto mine_l = [&](int v) -> bool { if constexpr (RECOMPUTE_SHARE) return __builtin_amdgcn_inverse_ballot_w64(mineL[v]); else return lcol[v] != NOT_MINE; };
     auto mine_r = [&](int v) -> bool { if constexpr (RECOMPUTE_SHARE) return __builtin_amdgcn_inverse_ballot_w64(mineR[v]); else return rcol[v] != NOT_MINE; };
     unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
@@ -738,10 +834,23 @@ struct Cw {                                         // P columns per lane: 4 (pa
           // one resource per row (scalar arithmetic): base = the row, num_records = its width
           const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lrow), 0, j.w, 0x00020000);
           const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(rrow), 0, j.w, 0x00020000);
+          if constexpr (TR3) {
+            // one (unaligned) dword per pixel triple.  A wave that streams positions at the row's ends loads
+            // the nearest dword inside the row instead (a partly outside dword would read as 0 whole) and
+            // shifts the bytes into place when it lands them (land_row).
+            const int last = j.w - 4;
 #pragma unroll
-          for (int v = 0; v < MAXL; ++v) pfl[v] = __builtin_amdgcn_raw_buffer_load_b8(rsL, lcol[v], 0, 0);
+            for (int v = 0; v < MAXL; ++v)
+              pfl[v] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsL, whole_words ? lcol[v] : min(max(lcol[v], 0), last), 0, 0);
 #pragma unroll
-          for (int v = 0; v < MAXR; ++v) pfr[v] = __builtin_amdgcn_raw_buffer_load_b8(rsR, rcol[v], 0, 0);
+            for (int v = 0; v < MAXR; ++v)
+              pfr[v] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsR, whole_words ? rcol[v] : min(max(rcol[v], 0), last), 0, 0);
+          } else {
+#pragma unroll
+            for (int v = 0; v < MAXL; ++v) pfl[v] = __builtin_amdgcn_raw_buffer_load_b8(rsL, lcol[v], 0, 0);
+#pragma unroll
+            for (int v = 0; v < MAXR; ++v) pfr[v] = __builtin_amdgcn_raw_buffer_load_b8(rsR, rcol[v], 0, 0);
+          }
         } else {
           // the unpacked variants run at their register limit; there the plain loads allocate better
           // (B16 D64: 35.4 us against 39.9 with buffer loads)
@@ -758,6 +867,22 @@ struct Cw {                                         // P columns per lane: 4 (pa
       }
     };
     auto land_row = [&](Px* dst) {
+      if constexpr (TR3) {
+        // the triple of column c from the dword loaded at column ld: shifted by c - ld bytes, zeros moving in
+        auto place = [&](unsigned dw, int col) -> unsigned {
+          if (whole_words) return dw & 0xffffffu;
+          const int k = col - min(max(col, 0), j.w - 4);    // < 0 at the row's left end, > 0 at its right end
+          const int sl = k < 0 ? min(-k, 7) * 8 : 0, sr = k > 0 ? min(k, 7) * 8 : 0;
+          return (unsigned)(((unsigned long long)dw << sl) >> sr) & 0xffffffu;
+        };
+#pragma unroll
+        for (int v = 0; v < MAXL; ++v)
+          if (mine_l(v)) dst[il0 + 64 * v] = (Px)place(pfl[v], lcol[v]);
+#pragma unroll
+        for (int v = 0; v < MAXR; ++v)
+          if (mine_r(v)) dst[TW + ir0 + 64 * v] = (Px)place(pfr[v], rcol[v]);
+        return;
+      }
 #pragma unroll
       for (int v = 0; v < MAXL; ++v)
         if (mine_l(v)) dst[il0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfl[v]) : PK ? pfl[v] : pfl[v] << a.pixshift);
@@ -846,8 +971,13 @@ struct Cw {                                         // P columns per lane: 4 (pa
       const bool in = col >= 0 && col < j.w;
       if constexpr (PK) {
         if (!use_pen || !in) return 0u;
-        if (d > j.maxdisp) return (j.w - 1 - col) % B1 == 0 ? PEN : 0u;
-        return (col < d && (d - 1 - col) % B1 == 0) ? PEN : 0u;
+        // TR3: the register of column c sums the columns c, c+1, c+2, and a window is the registers of
+        // c0, c0+3, ... (c0 = x-h): the penalised class is three consecutive columns of every 2h+1, so that
+        // again exactly one register of a window is in it (the residues of c0, c0+3, ... mod 2h+1 fall into
+        // the (2h+1)/3 different thirds) -- and it is < d whenever c0 is.
+        constexpr int CW = TR3 ? 3 : 1;
+        if (d > j.maxdisp) return (j.w - 1 - col) % B1 < CW ? PEN : 0u;
+        return (col < d && (d - 1 - col) % B1 < CW) ? PEN : 0u;
       } else if constexpr (FL) {
         // f32 sums: the biased column class carries (candidate index within the pass) / 256 -- the sums
         // stay exact while (2h+1)^2 * 255 * 256 < 2^24 (h <= 7) -- and a penalised column 2^16, above
@@ -980,8 +1110,15 @@ struct Cw {                                         // P columns per lane: 4 (pa
 
 
 // WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
-template <int P, int ND, int H, bool PK, int WB, bool W16, bool FL = false>
-__global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK, W16, FL>::run(a); }
+// TR: the triple-column form (Cw::TR3); launched for the tiles that do not hold the image's last two columns.
+template <int P, int ND, int H, bool PK, int WB, bool W16, bool FL = false, bool TR = false>
+__global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK, W16, FL, TR>::run(a); }
+
+#ifdef SADHIP_NO_TR3
+constexpr bool kTripleColumns = false;
+#else
+constexpr bool kTripleColumns = true;
+#endif
 
 struct Plan { int p, nd, nw; bool pk, extra, w16; bool fl = false; };
 
@@ -1008,7 +1145,7 @@ int env_int(const char* name, int dflt)
     static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
-                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS"};
+                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -1212,10 +1349,13 @@ static int wgs_per_cu(Kernel kernel, int threads, size_t lds)
 // dry: run every host-side check (instantiation exists, per-wave shares fit, LDS fits) and return
 // without launching -- what fast_supported() asks, so that a job the column-wave kernel cannot run
 // is routed to the generic kernel at PLANNING time and never by a silent fallback after a failure.
-template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false, bool FL = false>
-hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry)
+// part: 0 = every tile of the job; 1 = only the tiles before the first one that holds the image's last two
+// columns (the triple-column form, TR); 2 = only the tiles from that one on (the plain form next to it).
+template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false, bool FL = false, bool TR = false>
+hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, int part = 0)
 {
-  using K = Cw<P, ND, H, PK, W16, FL>;
+  using K = Cw<P, ND, H, PK, W16, FL, TR>;
+  static_assert(!TR || !FL, "");
   if (FL && (io.kin || io.kout)) return hipErrorInvalidValue;   // float keys do not travel between passes
   CwArgs a{};
   a.j = j;
@@ -1244,6 +1384,13 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   while (a.tx0 + (k0 + 1) * K::STEP + K::OL <= j.x0) ++k0;   // tile k0 ends after x0
   k1 = k0;
   while (a.tx0 + (k1 + 1) * K::STEP + K::OL < j.x1) ++k1;
+  if (part != 0) {
+    int ke = 0;                                               // first tile whose lanes hold column w-2 or w-1
+    while (a.tx0 + ke * K::STEP + K::TW + 2 <= j.w) ++ke;
+    if (part == 1) k1 = std::min(k1, ke - 1); else k0 = std::max(k0, ke);
+    if (k1 < k0) return hipSuccess;                           // no tile of this kind in the job
+  }
+  if (TR && part != 1) return hipErrorInvalidValue;
   const int ntiles = k1 - k0 + 1;
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
@@ -1269,7 +1416,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   } else if (env_int("SADHIP_TUNE_STRIPS", 0) > 0) {
     nstrips = env_int("SADHIP_TUNE_STRIPS", 0);
   } else {
-    nstrips = choose_strips(base, rows, 2 * H, cu_count(), wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL>, 64 * pl.nw, lds), min_rows);
+    nstrips = choose_strips(base, rows, 2 * H, cu_count(), wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL, TR>, 64 * pl.nw, lds), min_rows);
   }
   const long max_strips = (rows + min_rows - 1) / min_rows;
   if (nstrips > max_strips) nstrips = max_strips;
@@ -1278,7 +1425,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   nstrips = (rows + a.th - 1) / a.th;
   if (env_int("SADHIP_TUNE_VERBOSE", 0))
     fprintf(stderr, "sadhip: P%d ND%d H%d nw%d: %ld strips of %d rows x %ld workgroups per layer, %d per CU, lds %zu\n", P, ND, H, pl.nw, nstrips, a.th,
-            base, wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL>, 64 * pl.nw, lds), lds);
+            base, wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL, TR>, 64 * pl.nw, lds), lds);
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     CwArgs aa = a;
     aa.j.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
@@ -1297,7 +1444,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
       else (void)hipMemsetAsync(aa.stamps, 0, nwg * 16 * 8 * sizeof(unsigned long long), s);
     }
 #endif
-    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, FL>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, FL, TR>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef SADHIP_STAMPS
@@ -1374,7 +1521,11 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   if (pl.w16 && !pl.pk && h == 15) return launch_t<8, 8, 15, false, 1024, true>(j, pl, io, s, dry);
   if (pl.p == 8 && pl.nd == 8 && h == 7 && pl.pk) return launch_t<8, 8, 7, true>(j, pl, io, s, dry);
   if (pl.p == 8 && pl.nd == 8 && h == 5 && !pl.pk) return launch_t<8, 8, 5, false, 1024>(j, pl, io, s, dry);
-  if (pl.p == 4 && pl.nd == 16 && h == 4 && pl.pk) return launch_t<4, 16, 4, true>(j, pl, io, s, dry);
+  if (pl.p == 4 && pl.nd == 16 && h == 4 && pl.pk) {
+    if (!kTripleColumns || (!dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, 16, 4, true>(j, pl, io, s, dry);
+    const hipError_t e1 = launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1);
+    return e1 != hipSuccess ? e1 : launch_t<4, 16, 4, true>(j, pl, io, s, dry, 2);
+  }
   if (pl.p == 4 && pl.nd == 16 && h == 7 && pl.pk) return launch_t<4, 16, 7, true>(j, pl, io, s, dry);
   return hipErrorInvalidValue;
 #else
@@ -1384,7 +1535,14 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   SADHIP_W16U(9); SADHIP_W16U(10); SADHIP_W16U(11); SADHIP_W16U(12); SADHIP_W16U(13); SADHIP_W16U(14); SADHIP_W16U(15);
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
   if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s, dry)
-#define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_CASE(4, NDD, 4, true)
+  // BlockSize 9: triple-column form for the tiles left of the image's last two columns, plain form for the rest
+#define SADHIP_B9(NDD) \
+  if (pl.p == 4 && pl.nd == NDD && h == 4 && pl.pk) { \
+    if (!kTripleColumns || (!dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, NDD, 4, true>(j, pl, io, s, dry); \
+    const hipError_t e1 = launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1); \
+    return e1 != hipSuccess ? e1 : launch_t<4, NDD, 4, true>(j, pl, io, s, dry, 2); \
+  }
+#define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_B9(NDD)
 #define SADHIP_P8(NDD) SADHIP_CASE(8, NDD, 5, true); SADHIP_CASE(8, NDD, 6, true); SADHIP_CASE(8, NDD, 7, true)
   SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
   SADHIP_P8(4); SADHIP_P8(8); SADHIP_CASE(8, 12, 5, true);

@@ -437,6 +437,38 @@ def test_device_resident_batch(ctx):
         assert np.array_equal(out[i].cpu().numpy(), _expect(L, R, 9, 64))
 
 
+def test_block9_batches_triple_column_form(ctx):
+    """BlockSize 9 in batches of >= 48 pairs runs two kernels per pass (kernels_fast.hip, Cw::TR3): the
+    triple-column form for the tiles left of the image's last two columns, the plain form for the rest.
+    Widths around every tile-split boundary (258 = one tile + 2, 506 = two tiles + 2, ...) and every
+    w mod 4, single- and multi-pass disparity ranges, random / shifted / extreme / flat frames, a region;
+    every frame against the oracle or the generic kernel (itself pinned to the oracle above)."""
+    import torch
+    n = 64
+    rng = np.random.default_rng(909)
+    for w, h, D in ((257, 20, 16), (258, 20, 64), (259, 22, 64), (505, 20, 64), (506, 20, 64), (507, 21, 33), (600, 24, 128),
+                    (745, 20, 64), (1001, 18, 64), (530, 20, 200), (1920, 12, 64)):
+        Lb = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+        Rb = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+        s = min(D, 37)
+        Rb[1] = np.roll(Lb[1], -s, axis=1)                      # a true shift
+        Lb[2] = 255; Rb[2] = 0; Rb[2][:, w // 2:] = 255         # the largest possible SADs
+        Lb[3] = 77; Rb[3] = 77                                   # flat: every candidate ties
+        Rb[4] = Lb[4]                                            # identical: SAD 0 at d = 0
+        Ls, Rs = torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda()
+        out = torch.full_like(Ls, 0xCD)
+        ref = torch.full_like(Ls, 0xEE)
+        raw = capi.FLAG_RAW if D <= 255 else 0
+        ctx.disparity_dev(Ls, Rs, out, 9, D, raw)
+        assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+        ctx.disparity_dev(Ls, Rs, ref, 9, D, raw | capi.FLAG_FORCE_GENERIC)
+        torch.cuda.synchronize()
+        got, exp = out.cpu().numpy(), ref.cpu().numpy()
+        assert np.array_equal(got, exp), (w, h, D, np.argwhere(got != exp)[:4])
+        for i in (0, 1, 2, n - 1):                               # and against the oracle itself
+            assert np.array_equal(got[i], _expect(Lb[i], Rb[i], 9, D, raw=bool(raw))), (w, D, i)
+
+
 def test_multi_pass_batch_beyond_one_grid(ctx):
     """a multi-pass job (D + 1 > 129 candidates: a u32 key per pixel travels between the
     passes) over more frames than one sub-launch covers (32768): the key rows of the later

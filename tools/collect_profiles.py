@@ -50,7 +50,7 @@ tj = {"_comment": "HBM traffic and VALU instruction count of one batched launch 
                   "from rocprofv3 --pmc (separate passes; profiles/%s_c3.md). gfx950 correction per MI355X_MICROARCH.md "
                   "(FETCH_SIZE x2, WRITE_SIZE x1; re-calibrated in round 1 on known-byte kernels, tools/ubench/hbm_calib.hip)." % tag,
       "round": int(re.sub(r"\D", "", tag) or 0), "source": f"profiles/{tag}_c3.md", "source_digest": digest,
-      "frames_per_launch": 128, "width": 1920, "height": 1080, "block": 9, "maxdisp": 64,
+      "frames_per_launch": 1024, "width": 1920, "height": 1080, "block": 9, "maxdisp": 64,
       "fetch_size_kb": fetch, "write_size_kb": write, "fetch_correction": 2.0, "write_correction": 1.0,
       "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "sq_insts_valu_per_launch": int(insts)}
 json.dump(tj, open(os.path.join(pr, "traffic.json"), "w"), indent=1)
@@ -58,5 +58,5 @@ print("profiles/traffic.json", tj["hbm_bytes_per_launch"], tj["sq_insts_valu_per
 plan = subprocess.check_output([sys.executable, "-c",
                                 "import sys; sys.path.insert(0, %r); import steroscopic_hardware_amd as s; print(s.capi.plan_describe(1920,1080,9,64))" % REPO], text=True)
 pl = eval(plan.strip())[0]
-sys.argv = ["valu_budget.py", str(pl["p"]), str(pl["nd"]), "4", str(pl["packed"]), "1024", str(pl["w16"]), "--json", os.path.join(pr, "valu_budget.json")]
+sys.argv = ["valu_budget.py", str(pl["p"]), str(pl["nd"]), "4", str(pl["packed"]), "1024", str(pl["w16"]), "1" if (pl["p"] == 4 and pl["packed"]) else "0", "--json", os.path.join(pr, "valu_budget.json")]
 valu_budget.main()

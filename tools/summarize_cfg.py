@@ -44,7 +44,7 @@ if os.path.exists(tr):
     for r in rows:
         r["_d"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     if rows:
-        thr = max(r["_d"] for r in rows) / 4
+        thr = max(r["_d"] for r in rows) / 50        # (a job may be two kernels of very different size: the BlockSize-9 tile split)
         big = [r for r in rows if r["_d"] > thr]
         by_kernel = collections.defaultdict(list)
         for r in big:
@@ -87,7 +87,7 @@ for p in ("pmc_sq", "pmc_fetch", "pmc_write"):
     for r in rows:
         per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
         dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    thr = max(dur.values()) / 4
+    thr = max(dur.values()) / 50
     # one job may be several kernels (passes): sum the counters of the big dispatches, divide by jobs
     bigs = [d for d in per if dur[d] > thr]
     names = collections.Counter(r["Kernel_Name"] for r in rows if dur[r["Dispatch_Id"]] > thr and r["Counter_Name"] == rows[0]["Counter_Name"])

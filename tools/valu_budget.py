@@ -2,7 +2,8 @@
 """Per-wave-step instruction budget of a column-wave kernel instantiation, from the compiler's
 assembly (hipcc -S of csrc/kernels_fast.hip), by issue class.
 
-  tools/valu_budget.py [P ND H PK WB W16] [--asm lib/kernels_fast.s] [--json out.json] [--blocks]
+  tools/valu_budget.py [P ND H PK WB W16 [TR]] [--asm lib/kernels_fast.s] [--json out.json] [--blocks]
+  (TR = 1: the triple-column form of the BlockSize-9 kernels, the one that runs all tiles but the image's last)
 
 The row loop is the largest natural loop of the kernel (back edge with the widest span).  Every
 instruction in it is put into one class; the class costs are the ones measured on MI355X by
@@ -156,16 +157,17 @@ def summarise(inss):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("variant", nargs="*", default=["4", "16", "4", "1", "1024", "0"], help="P ND H PK WB W16")
+    ap.add_argument("variant", nargs="*", default=["4", "16", "4", "1", "1024", "0", "1"], help="P ND H PK WB W16 [TR]")
     ap.add_argument("--asm", default=os.path.join(LIBD, "kernels_fast.s"))
     ap.add_argument("--json")
     ap.add_argument("--blocks", action="store_true")
     ap.add_argument("-D", dest="defs", action="append", default=[], help="extra -D for the compile (e.g. SADHIP_EXPERIMENT: only the kernels under study)")
     a = ap.parse_args()
-    P, ND, H, PK, WB, W16 = (int(v) for v in a.variant)
+    P, ND, H, PK, WB, W16 = (int(v) for v in a.variant[:6])
+    TR = int(a.variant[6]) if len(a.variant) > 6 else 0
     ensure_asm(a.asm, a.defs)
     asm = open(a.asm).read()
-    sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb0EEEvNS0_6CwArgsE"
+    sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb0ELb{TR}EEEvNS0_6CwArgsE"
     blocks = analyse(kernel_body(asm, sym))
     main_ins, xtra_ins = [], []
     # the extra-candidate path = the blocks from the kernel's SADHIP_XTRA_BEGIN marker to its SADHIP_XTRA_END
@@ -193,7 +195,7 @@ def main():
     cyc = sum(cnt[k] * COST[k] for k in COST)
     slots = P * ND * (1 if not PK else 1)          # (column, candidate) pairs per lane per step = wave-wide slots of 64 candidates
     res = {
-        "kernel": f"k_colwave<{P},{ND},{H},{'true' if PK else 'false'},{WB},{'true' if W16 else 'false'}>",
+        "kernel": f"k_colwave<{P},{ND},{H},{'true' if PK else 'false'},{WB},{'true' if W16 else 'false'}{',triple-column' if TR else ''}>",
         "source_digest": source_digest(),
         "class_cost_cycles": COST,
         "row_loop_common_path": {"counts": cnt, "valu_instructions": valu, "ideal_simd_cycles": cyc,
