@@ -224,13 +224,20 @@ def main():
     # kernel sources (profiles/traffic.json, profiles/valu_budget.json carry the digest of csrc/); a
     # profile of other sources is reported as stale, never as current.
     digest = _source_digest()
+    same_shape, scale = False, 1.0
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        same_shape = (tj["frames_per_launch"], tj["width"], tj["height"], tj["block"], tj["maxdisp"]) == (F, W, H, block, maxdisp)
+        # same frame shape and parameters, and a batch that takes the same kernels (>= 48 pairs: the BlockSize-9 tile
+        # split): counters are per pair x this step's pairs.  (rocprofv3 --pmc crashes inside torch's generator kernels
+        # with 1024 resident 1080p pairs on this pool; the profile is taken at 256.)
+        same_shape = (tj["width"], tj["height"], tj["block"], tj["maxdisp"]) == (W, H, block, maxdisp) and \
+            (tj["frames_per_launch"] == F or min(tj["frames_per_launch"], F) >= 48)
+        scale = F / tj["frames_per_launch"]
         if same_shape and res["config"]["kernel_kind"] == 1:
             if tj.get("source_digest") == digest:
-                res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                res["roofline"]["traffic_source"] = tj.get("source", "profiles/traffic.json")
+                res["roofline"]["traffic"] = int(tj["hbm_bytes_per_launch"] * scale)
+                res["roofline"]["traffic_source"] = tj.get("source", "profiles/traffic.json") + \
+                    ("" if scale == 1 else " (measured at %d pairs per launch, scaled per pair to %d)" % (tj["frames_per_launch"], F))
             else:
                 res["roofline"]["traffic_source"] = "stale: profiles/traffic.json was measured on other kernel sources (digest %s, now %s)" % (tj.get("source_digest"), digest)
     except (OSError, KeyError, ValueError):
@@ -249,10 +256,9 @@ def main():
                         "(fast 2, slow 4, s_nop 4 cycles per wave-instruction per SIMD, measured by tools/ubench/valu_rates*.hip)"}
         if vb.get("source_digest") != digest:
             valu["budget_source"] += " -- STALE (digest %s, sources now %s)" % (vb.get("source_digest"), digest)
-        if tj and tj.get("source_digest") == digest and "sq_insts_valu_per_launch" in tj and \
-                (tj["frames_per_launch"], tj["width"], tj["height"], tj["block"], tj["maxdisp"]) == (F, W, H, block, maxdisp):
-            ginst = tj["sq_insts_valu_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
-            valu.update({"achieved": ginst, "insts_per_launch": tj["sq_insts_valu_per_launch"],
+        if tj and tj.get("source_digest") == digest and "sq_insts_valu_per_launch" in tj and same_shape:
+            ginst = tj["sq_insts_valu_per_launch"] * scale / (avg_launch_ms * 1e-3) / 1e9
+            valu.update({"achieved": ginst, "insts_per_launch": int(tj["sq_insts_valu_per_launch"] * scale),
                          "frac_of_vector_peak": ginst / VECTOR_PEAK_GWINST, "frac_of_mix_ceiling": ginst / valu["mix_ceiling"],
                          "insts_source": "SQ_INSTS_VALU of " + tj.get("source", "profiles/traffic.json")})
         res["roofline"]["valu"] = valu

@@ -11,7 +11,8 @@ elif any(k.startswith("SADHIP_TUNE_") for k in os.environ):      # the knobs exi
     sha.capi.LIB_PATH = os.path.join(os.path.dirname(sha.capi.LIB_PATH), "libsadhip_tune.so")
 W, H, B, D = (int(v) for v in sys.argv[1:5]); N = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 dev = torch.device("cuda", 0)
-Ls, Rs = sha.synth.synth_batch_torch([1000 + i for i in range(N)], W, H, dev)
+_parts = [sha.synth.synth_batch_torch([1000 + i for i in range(c, min(c + 128, N))], W, H, dev) for c in range(0, N, 128)]   # in chunks of 128: bounded temporaries
+Ls, Rs = torch.cat([p[0] for p in _parts]), torch.cat([p[1] for p in _parts]); del _parts
 out = torch.empty_like(Ls)
 ctx = sha.capi.Context(0, W, H, 1)
 for _ in range(2): ctx.disparity_dev(Ls, Rs, out, B, D)

@@ -50,7 +50,7 @@ tj = {"_comment": "HBM traffic and VALU instruction count of one batched launch 
                   "from rocprofv3 --pmc (separate passes; profiles/%s_c3.md). gfx950 correction per MI355X_MICROARCH.md "
                   "(FETCH_SIZE x2, WRITE_SIZE x1; re-calibrated in round 1 on known-byte kernels, tools/ubench/hbm_calib.hip)." % tag,
       "round": int(re.sub(r"\D", "", tag) or 0), "source": f"profiles/{tag}_c3.md", "source_digest": digest,
-      "frames_per_launch": 1024, "width": 1920, "height": 1080, "block": 9, "maxdisp": 64,
+      "frames_per_launch": 256, "width": 1920, "height": 1080, "block": 9, "maxdisp": 64,
       "fetch_size_kb": fetch, "write_size_kb": write, "fetch_correction": 2.0, "write_correction": 1.0,
       "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "sq_insts_valu_per_launch": int(insts)}
 json.dump(tj, open(os.path.join(pr, "traffic.json"), "w"), indent=1)

@@ -9,8 +9,8 @@ set -u
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-tools/profile_cfg.sh ${TAG}_c3 1920 1080 9 64 1024
-PMC_SQ="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM" tools/profile_cfg.sh ${TAG}_c3w 1920 1080 9 64 1024
+tools/profile_cfg.sh ${TAG}_c3 1920 1080 9 64 256      # (rocprofv3 --pmc crashes in torch's generator kernels at 1024 resident pairs)
+PMC_SQ="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM" tools/profile_cfg.sh ${TAG}_c3w 1920 1080 9 64 256
 tools/profile_cfg.sh ${TAG}_c5 3840 2160 15 128 16
 PMC_SQ="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM" tools/profile_cfg.sh ${TAG}_c5w 3840 2160 15 128 16
 tools/profile_cfg.sh ${TAG}_c2 640 480 7 32 128

@@ -11,13 +11,13 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/trace.log 2>&1
+timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/trace.log 2>&1
 echo "[$TAG] trace exit=$? $(tail -1 $OUT/trace.log)"
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc ${PMC_SQ:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES} GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_sq.log 2>&1
+timeout -k 10 420 rocprofv3 --kernel-trace --pmc ${PMC_SQ:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES} GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_sq.log 2>&1
 echo "[$TAG] pmc sq exit=$?"
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 420 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_fetch.log 2>&1
 echo "[$TAG] pmc fetch exit=$?"
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_write.log 2>&1
+timeout -k 10 420 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_write.log 2>&1
 echo "[$TAG] pmc write exit=$?"
 # keep only the disparity kernels' rows of the big CSVs (torch's generator kernels dominate them):
 # gpurun copies back at most 64 MiB
