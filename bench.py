@@ -210,9 +210,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": None,
                      "kernel_avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                     "note": "path is integer-VALU bound (SURVEY 8d); see gcand_per_s and DESIGN.md. A step at BlockSize 9 is two "
-                             "kernels on one stream (triple-column form for the tiles left of the image's last two columns, plain "
-                             "form for the last tile); kernel_avg_launch_ms spans both"},
+                     "note": "path is integer-VALU bound (SURVEY 8d); see gcand_per_s and DESIGN.md. At BlockSize 9 the kernel holds "
+                             "two forms of the row loop (triple-column for the tiles left of the image's last two columns, plain for "
+                             "the last tile) and picks per workgroup"},
     }
 
     ran = sha.capi.last_kernel_kind()                             # what the timed launches really ran (no silent fallback)
@@ -227,9 +227,9 @@ def main():
     same_shape, scale = False, 1.0
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        # same frame shape and parameters, and a batch that takes the same kernels (>= 48 pairs: the BlockSize-9 tile
-        # split): counters are per pair x this step's pairs.  (rocprofv3 --pmc crashes inside torch's generator kernels
-        # with 1024 resident 1080p pairs on this pool; the profile is taken at 256.)
+        # same frame shape and parameters, a large batch in both: counters are per pair x this step's pairs.
+        # (rocprofv3 --pmc crashes inside torch's generator kernels with 1024 resident 1080p pairs on this pool; the
+        # profile is taken at 256.)
         same_shape = (tj["width"], tj["height"], tj["block"], tj["maxdisp"]) == (W, H, block, maxdisp) and \
             (tj["frames_per_launch"] == F or min(tj["frames_per_launch"], F) >= 48)
         scale = F / tj["frames_per_launch"]

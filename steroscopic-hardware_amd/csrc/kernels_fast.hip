@@ -818,9 +818,9 @@ struct Cw {                                         // P columns per lane: 4 (pa
     if constexpr (TR3) {
       bool ok = true;
 #pragma unroll
-      for (int v = 0; v < MAXL; ++v) ok = ok && (lcol[v] == NOT_MINE || (lcol[v] >= 0 && lcol[v] <= j.w - 4));
+      for (int v = 0; v < MAXL; ++v) ok = ok && (lcol[v] == NOT_MINE || lcol[v] >= 0);      // (<= w-4 by the tile split)
 #pragma unroll
-      for (int v = 0; v < MAXR; ++v) ok = ok && (rcol[v] == NOT_MINE || (rcol[v] >= 0 && rcol[v] <= j.w - 4));
+      for (int v = 0; v < MAXR; ++v) ok = ok && (rcol[v] == NOT_MINE || rcol[v] >= 0);
       whole_words = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
     }
     auto mine_l = [&](int v) -> bool { if constexpr (RECOMPUTE_SHARE) return __builtin_amdgcn_inverse_ballot_w64(mineL[v]); else return lcol[v] != NOT_MINE; };
@@ -835,16 +835,16 @@ struct Cw {                                         // P columns per lane: 4 (pa
           const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lrow), 0, j.w, 0x00020000);
           const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(rrow), 0, j.w, 0x00020000);
           if constexpr (TR3) {
-            // one (unaligned) dword per pixel triple.  A wave that streams positions at the row's ends loads
-            // the nearest dword inside the row instead (a partly outside dword would read as 0 whole) and
-            // shifts the bytes into place when it lands them (land_row).
-            const int last = j.w - 4;
+            // one (unaligned) dword per pixel triple.  Tiles in this form never reach the row's right end
+            // (launch_t); at its left end a dword that starts at column -1 or -2 is partly outside and would
+            // read as 0 whole, while it holds the pixels 0, 1: a wave that streams such positions loads the
+            // dword of column 0 for them and shifts when it lands it (columns <= -3: all outside, 0 is right).
 #pragma unroll
             for (int v = 0; v < MAXL; ++v)
-              pfl[v] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsL, whole_words ? lcol[v] : min(max(lcol[v], 0), last), 0, 0);
+              pfl[v] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsL, whole_words ? lcol[v] : max(lcol[v], min(lcol[v] + 2, 0)), 0, 0);
 #pragma unroll
             for (int v = 0; v < MAXR; ++v)
-              pfr[v] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsR, whole_words ? rcol[v] : min(max(rcol[v], 0), last), 0, 0);
+              pfr[v] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsR, whole_words ? rcol[v] : max(rcol[v], min(rcol[v] + 2, 0)), 0, 0);
           } else {
 #pragma unroll
             for (int v = 0; v < MAXL; ++v) pfl[v] = __builtin_amdgcn_raw_buffer_load_b8(rsL, lcol[v], 0, 0);
@@ -868,12 +868,11 @@ struct Cw {                                         // P columns per lane: 4 (pa
     };
     auto land_row = [&](Px* dst) {
       if constexpr (TR3) {
-        // the triple of column c from the dword loaded at column ld: shifted by c - ld bytes, zeros moving in
+        // the triple of column c from the dword loaded at column ld >= c: moved up by ld - c (0..2) bytes
         auto place = [&](unsigned dw, int col) -> unsigned {
           if (whole_words) return dw & 0xffffffu;
-          const int k = col - min(max(col, 0), j.w - 4);    // < 0 at the row's left end, > 0 at its right end
-          const int sl = k < 0 ? min(-k, 7) * 8 : 0, sr = k > 0 ? min(k, 7) * 8 : 0;
-          return (unsigned)(((unsigned long long)dw << sl) >> sr) & 0xffffffu;
+          const int up = max(col, min(col + 2, 0)) - col;
+          return (dw << (8 * up)) & 0xffffffu;
         };
 #pragma unroll
         for (int v = 0; v < MAXL; ++v)
@@ -1112,7 +1111,16 @@ struct Cw {                                         // P columns per lane: 4 (pa
 // WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
 // TR: the triple-column form (Cw::TR3); launched for the tiles that do not hold the image's last two columns.
 template <int P, int ND, int H, bool PK, int WB, bool W16, bool FL = false, bool TR = false>
-__global__ void __launch_bounds__(WB) k_colwave(CwArgs a) { Cw<P, ND, H, PK, W16, FL, TR>::run(a); }
+__global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
+{
+  if constexpr (TR) {                                         // per workgroup: the tile with the image's last two columns runs the plain form
+    using K = Cw<P, ND, H, PK, W16, FL, true>;
+    const int tx = a.tx0 + ((int)blockIdx.y + a.tile0) * K::STEP;
+    if (tx + K::TW + 2 <= a.j.w) K::run(a); else Cw<P, ND, H, PK, W16, FL, false>::run(a);
+  } else {
+    Cw<P, ND, H, PK, W16, FL, false>::run(a);
+  }
+}
 
 #ifdef SADHIP_NO_TR3
 constexpr bool kTripleColumns = false;
@@ -1145,7 +1153,7 @@ int env_int(const char* name, int dflt)
     static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
-                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN"};
+                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -1390,7 +1398,6 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
     if (part == 1) k1 = std::min(k1, ke - 1); else k0 = std::max(k0, ke);
     if (k1 < k0) return hipSuccess;                           // no tile of this kind in the job
   }
-  if (TR && part != 1) return hipErrorInvalidValue;
   const int ntiles = k1 - k0 + 1;
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
@@ -1522,7 +1529,9 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   if (pl.p == 8 && pl.nd == 8 && h == 7 && pl.pk) return launch_t<8, 8, 7, true>(j, pl, io, s, dry);
   if (pl.p == 8 && pl.nd == 8 && h == 5 && !pl.pk) return launch_t<8, 8, 5, false, 1024>(j, pl, io, s, dry);
   if (pl.p == 4 && pl.nd == 16 && h == 4 && pl.pk) {
-    if (!kTripleColumns || (!dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, 16, 4, true>(j, pl, io, s, dry);
+    const int trmode = kTripleColumns ? env_int("SADHIP_TUNE_TRMODE", 2) : 0;
+    if (trmode == 0 || (trmode == 1 && !dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, 16, 4, true>(j, pl, io, s, dry);
+    if (trmode == 2) return launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 0);
     const hipError_t e1 = launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1);
     return e1 != hipSuccess ? e1 : launch_t<4, 16, 4, true>(j, pl, io, s, dry, 2);
   }
@@ -1538,7 +1547,9 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   // BlockSize 9: triple-column form for the tiles left of the image's last two columns, plain form for the rest
 #define SADHIP_B9(NDD) \
   if (pl.p == 4 && pl.nd == NDD && h == 4 && pl.pk) { \
-    if (!kTripleColumns || (!dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, NDD, 4, true>(j, pl, io, s, dry); \
+    const int trmode = kTripleColumns ? env_int("SADHIP_TUNE_TRMODE", 2) : 0;   /* 0 plain, 1 two launches split by tile, 2 one kernel that picks per workgroup */ \
+    if (trmode == 0 || (trmode == 1 && !dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, NDD, 4, true>(j, pl, io, s, dry); \
+    if (trmode == 2) return launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 0); \
     const hipError_t e1 = launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1); \
     return e1 != hipSuccess ? e1 : launch_t<4, NDD, 4, true>(j, pl, io, s, dry, 2); \
   }

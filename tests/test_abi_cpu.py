@@ -80,6 +80,7 @@ def test_no_column_wave_kernel_spills():
     select spilled 14-21 VGPRs, 60-88 bytes of scratch per lane).  SGPR -> VGPR-lane parking (no memory
     traffic) is tolerated only in the lane-mask families (packed h = 6, 7: up to 7 64-bit masks live across
     the row loop on top of a kernel that already uses ~100 SGPRs), bounded at 12 (round 2 started at 13-25);
+    and in the BlockSize-9 kernels, which hold two forms of the row loop behind a per-workgroup branch (5-13);
     everything else reports 0 there too.  DESIGN.md section 6b has the measured alternatives."""
     import subprocess
     csrc = os.path.join(REPO, "steroscopic-hardware_amd", "csrc")
@@ -94,9 +95,11 @@ def test_no_column_wave_kernel_spills():
         name = b.split()[0]
         val = lambda k: int(re.search(k + r": (\d+)", b).group(1))
         sc, ss, vs = val(r"ScratchSize \[bytes/lane\]"), val("SGPRs Spill"), val("VGPRs Spill")
-        m = re.search(r"k_colwaveILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", name)
+        m = re.search(r"k_colwaveILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi\d+ELb\dELb\dELb(\d)E", name)
         lane_mask_family = bool(m) and m.group(4) == "1" and m.group(3) in ("6", "7")
-        if sc or vs or (ss and not lane_mask_family) or ss > 12:
+        # the BlockSize-9 kernels hold two forms behind a per-workgroup branch (triple-column / plain, Cw::TR3)
+        two_form_family = bool(m) and m.group(5) == "1"
+        if sc or vs or (ss and not (lane_mask_family or two_form_family)) or ss > (16 if two_form_family else 12):
             bad.append((name, sc, ss, vs))
     assert not bad, bad
 

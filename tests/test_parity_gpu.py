@@ -438,9 +438,9 @@ def test_device_resident_batch(ctx):
 
 
 def test_block9_batches_triple_column_form(ctx):
-    """BlockSize 9 in batches of >= 48 pairs runs two kernels per pass (kernels_fast.hip, Cw::TR3): the
-    triple-column form for the tiles left of the image's last two columns, the plain form for the rest.
-    Widths around every tile-split boundary (258 = one tile + 2, 506 = two tiles + 2, ...) and every
+    """BlockSize 9 runs two forms of the row loop in one kernel (kernels_fast.hip, Cw::TR3): workgroups of the
+    tiles left of the image's last two columns the triple-column form, the rest the plain form.
+    Widths around every tile boundary of that choice (258 = one tile + 2, 506 = two tiles + 2, ...) and every
     w mod 4, single- and multi-pass disparity ranges, random / shifted / extreme / flat frames, a region;
     every frame against the oracle or the generic kernel (itself pinned to the oracle above)."""
     import torch
