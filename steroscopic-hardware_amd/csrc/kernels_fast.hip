@@ -1032,6 +1032,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
 #define SADHIP_STAMP(K) do {} while (0)
 #define SADHIP_STAMP0() do {} while (0)
 #endif
+    asm volatile("; SADHIP_ROWLOOP form=%c0 (tools/valu_budget.py: 3 = triple-column, 1 = plain)" :: "n"(TR3 ? 3 : 1));
     for (int t = 0; t < nsteps; ++t) {
       if constexpr (RECOMPUTE_SHARE) {
         int ln = lane;

@@ -97,10 +97,18 @@ def classify(line):
     return op, cls
 
 
-def kernel_body(asm, sym):
+def kernel_body(asm, sym, form=None):
+    """The kernel's assembly lines; form (1 plain, 3 triple-column): only the part from that form's row-loop
+    marker to the next marker -- the BlockSize-9 kernels hold both forms of the row loop."""
     i = asm.index("\n" + sym + ":")
     j = asm.index(".Lfunc_end", i)
-    return asm[i:j].splitlines()
+    lines = asm[i:j].splitlines()
+    marks = [k for k, ln in enumerate(lines) if "SADHIP_ROWLOOP form=" in ln]
+    if form is not None and len(marks) > 1:
+        for n, k in enumerate(marks):
+            if f"form={form} " in lines[k]:
+                return lines[k:marks[n + 1] if n + 1 < len(marks) else len(lines)]
+    return lines
 
 
 def analyse(lines):
@@ -168,7 +176,7 @@ def main():
     ensure_asm(a.asm, a.defs)
     asm = open(a.asm).read()
     sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb0ELb{TR}EEEvNS0_6CwArgsE"
-    blocks = analyse(kernel_body(asm, sym))
+    blocks = analyse(kernel_body(asm, sym, 3 if TR else 1))
     main_ins, xtra_ins = [], []
     # the extra-candidate path = the blocks from the kernel's SADHIP_XTRA_BEGIN marker to its SADHIP_XTRA_END
     for b in blocks:
