@@ -538,6 +538,20 @@ struct Cw {                                         // P columns per lane: 4 (pa
       // left lane for i < 0 (T(i+P) there), of the right lane for i >= P.  Own-lane terms first, then the
       // left pulls, then (second sweep, as in the plain form) the right pulls: every pull is one DPP add.
       constexpr int M3 = (2 * H + 1) / 3;
+      if constexpr (H == 4 && P == 4) {
+        // the four windows by hand: T0 + T3 serves two of them (once as itself, once pulled from the left
+        // lane as a whole: left(T0) + left(T3) = left(T0 + T3)) -- 7 instructions instead of 8
+        const unsigned t0 = r.ps[1], t1 = r.ps[2], t2 = r.ps[3], t3 = r.ps[4];
+        const unsigned u = t0 + t3;
+        s[1] = u + from_left(t1);
+        s[2] = t1 + from_left(t2);
+        s[3] = t2 + from_left(t3);
+        s[0] = t2 + from_left(u);                              // (three instructions after u: no DPP hazard pad)
+#pragma unroll
+        for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
+        s[2] += from_right(t0);
+        s[3] += from_right(t1);
+      } else {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         bool have = false;
@@ -561,6 +575,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
           const int i = p - H + 3 * j;
           if (i >= P) s[p] += from_right(r.ps[i - P + 1]);
         }
+      }
     } else if constexpr (H <= P) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
