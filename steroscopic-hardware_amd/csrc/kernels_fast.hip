@@ -307,9 +307,9 @@ struct Cw {                                         // P columns per lane: 4 (pa
   // At the right image edge the form is wrong: the register of column w-2 (w-1) would also sum |0 - R| of
   // the columns w (w, w+1), which a clipped window of the reference does not contain -- R(x-d) is a real
   // pixel there, only L is outside the image.  (At the left edge both are outside: |0 - 0|.)  So a
-  // workgroup whose tile holds the columns w-2, w-1 runs the plain form (k_colwave picks per tile);
-  // TR is set for the other tiles of the BlockSize-9 kernels only.  (BlockSize 3, whose window IS one
-  // triple, measured slower in this form: two more byte loads per streamed pixel for no arithmetic saved
+  // workgroup whose tile holds the columns w-2, w-1 runs the plain form (k_colwave picks per workgroup);
+  // TR is set for the other workgroups of the BlockSize-9 kernels only.  (BlockSize 3, whose window IS one
+  // triple, measured slower in this form: more load traffic per streamed pixel for no arithmetic saved
   // that its small horizontal pass had not saved already.)
   static constexpr bool TR3 = TR;
   static_assert(!TR || (PK && P == 4 && !W16 && !FL && H == 4), "triple-column form: packed P = 4, h = 4");
@@ -827,13 +827,13 @@ struct Cw {                                         // P columns per lane: 4 (pa
     for (int v = 0; v < MAXL; ++v) mineL[v] = __builtin_amdgcn_ballot_w64(lane + 64 * v < a.shl && il0 + 64 * v < TW);
 #pragma unroll
     for (int v = 0; v < MAXR; ++v) mineR[v] = __builtin_amdgcn_ballot_w64(lane + 64 * v < a.shr && ir0 + 64 * v < RW);
-    // TR3: a pixel triple is one unaligned dword load where all three columns (and the byte after them) are
-    // inside the row for every position this wave streams; waves that touch the row's ends load bytes.
+    // TR3: a pixel triple is one unaligned dword load; a wave that streams a position left of column 0 takes the
+    // slower path of load_row / land_row for all its positions (wave-uniform choice, fixed for the workgroup's life)
     bool whole_words = false;
     if constexpr (TR3) {
       bool ok = true;
 #pragma unroll
-      for (int v = 0; v < MAXL; ++v) ok = ok && (lcol[v] == NOT_MINE || lcol[v] >= 0);      // (<= w-4 by the tile split)
+      for (int v = 0; v < MAXL; ++v) ok = ok && (lcol[v] == NOT_MINE || lcol[v] >= 0);      // (<= w-5: see load_row)
 #pragma unroll
       for (int v = 0; v < MAXR; ++v) ok = ok && (rcol[v] == NOT_MINE || rcol[v] >= 0);
       whole_words = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
@@ -850,8 +850,11 @@ struct Cw {                                         // P columns per lane: 4 (pa
           const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lrow), 0, j.w, 0x00020000);
           const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(rrow), 0, j.w, 0x00020000);
           if constexpr (TR3) {
-            // one (unaligned) dword per pixel triple.  Tiles in this form never reach the row's right end
-            // (launch_t); at its left end a dword that starts at column -1 or -2 is partly outside and would
+            // one (unaligned) dword per pixel triple.  Workgroups in this form never reach the row's right end:
+            // their last lane column is <= w-3 (k_colwave) and == w-1 (mod 4) like every tile's (tile origins
+            // == w mod 4), i.e. <= w-5, so the dword of every used position ends at column w-2 or before (the R
+            // part's spare last position may lie further right: it is never an operand).
+            // At the left end a dword that starts at column -1 or -2 is partly outside and would
             // read as 0 whole, while it holds the pixels 0, 1: a wave that streams such positions loads the
             // dword of column 0 for them and shifts when it lands it (columns <= -3: all outside, 0 is right).
 #pragma unroll
@@ -1125,7 +1128,8 @@ struct Cw {                                         // P columns per lane: 4 (pa
 
 
 // WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
-// TR: the triple-column form (Cw::TR3); launched for the tiles that do not hold the image's last two columns.
+// TR: the kernel holds both forms of the row loop (Cw::TR3): the triple-column form for the workgroups whose tile does
+// not hold the image's last two columns, the plain form for the others.
 template <int P, int ND, int H, bool PK, int WB, bool W16, bool FL = false, bool TR = false>
 __global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
 {

@@ -440,13 +440,15 @@ def test_device_resident_batch(ctx):
 def test_block9_batches_triple_column_form(ctx):
     """BlockSize 9 runs two forms of the row loop in one kernel (kernels_fast.hip, Cw::TR3): workgroups of the
     tiles left of the image's last two columns the triple-column form, the rest the plain form.
-    Widths around every tile boundary of that choice (258 = one tile + 2, 506 = two tiles + 2, ...) and every
+    Widths around every tile boundary of that choice (258 = one tile + 2, 260 / 508: a triple-form tile whose last
+    column is w-5, the closest it gets to the row's end, 506 = two tiles + 2, ...) and every
     w mod 4, single- and multi-pass disparity ranges, random / shifted / extreme / flat frames, a region;
     every frame against the oracle or the generic kernel (itself pinned to the oracle above)."""
     import torch
     n = 64
     rng = np.random.default_rng(909)
-    for w, h, D in ((257, 20, 16), (258, 20, 64), (259, 22, 64), (505, 20, 64), (506, 20, 64), (507, 21, 33), (600, 24, 128),
+    for w, h, D in ((257, 20, 16), (258, 20, 64), (259, 22, 64), (260, 20, 64), (261, 20, 64), (505, 20, 64), (506, 20, 64), (507, 21, 33),
+                    (508, 20, 64), (600, 24, 128),
                     (745, 20, 64), (1001, 18, 64), (530, 20, 200), (1920, 12, 64)):
         Lb = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
         Rb = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
