@@ -1236,14 +1236,20 @@ static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int
       const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
                        ((pk && h == 7) || (!pk && h >= 8 && maxdisp <= 255));
       // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
-      if (plan_lds_bytes(Plan{p, nd, nw, pk, false, w16}, h, maxdisp) > (size_t)160 * 1024) continue;
+      const size_t lds_plan = plan_lds_bytes(Plan{p, nd, nw, pk, false, w16}, h, maxdisp);
+      if (lds_plan > (size_t)160 * 1024) continue;
       const int slots = nw * nd;
       if (slots + 1 < count) continue;
       const bool extra = slots + 1 == count;
       if (exact && !extra && slots != count) continue;
       if (!extra && slots - nd >= count && nw > 4) continue;    // a whole wave would be idle
       const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
-      const long cost = (long)((nw + 3) / 4) * per_wave * 64 + nw;    // ties: fewer waves
+      // waves a CU can hold of this plan (LDS; 128 VGPRs = 16 waves for the unpacked kernels): with one
+      // 4-wave workgroup per CU nothing hides its latencies (measured: BlockSize 16, D 16 as 4 waves x 4
+      // candidates on a u32 ring, one workgroup per CU, 26.7 us; as 4 x 8 on the u16 ring, three per CU, 20.5)
+      const long resident = std::min<long>((long)((size_t)160 * 1024 / lds_plan) * nw, pk ? 20 : 16);
+      const long pct = resident <= 4 ? 200 : resident <= 8 ? 118 : 100;
+      const long cost = (long)((nw + 3) / 4) * per_wave * 64 * pct / 100 + nw;    // ties: fewer waves
       if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra, w16}; }
     }
   }
