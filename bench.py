@@ -181,6 +181,17 @@ def main():
         torch.cuda.synchronize(dev)
         one_ms.append(e0.elapsed_time(e1))
     one_ms = sorted(one_ms)[len(one_ms) // 2]
+    # ... and per pair at 128 pairs per launch (config 4's per-GPU share on 8 GPUs; what rounds 1 and 2a measured)
+    sub_ms = None
+    if F > 128:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx.disparity_dev(Ls[:128], Rs[:128], out[:128], block, maxdisp, args.flags, stream.cuda_stream)
+        e0.record(stream)
+        for _ in range(10):
+            ctx.disparity_dev(Ls[:128], Rs[:128], out[:128], block, maxdisp, args.flags, stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        sub_ms = e0.elapsed_time(e1) / 10 / 128
 
     if rank != 0:
         if dist is not None:
@@ -206,6 +217,7 @@ def main():
                    "kernel_kind": sha.capi.kernel_kind(W, H, block, maxdisp, args.flags)},
         "ms_per_frame": avg_launch_ms / F,
         "ms_per_frame_single_pair_latency": one_ms,
+        "ms_per_frame_at_128_pairs_per_launch": sub_ms,
         "gcand_per_s": cands * F / (avg_launch_ms * 1e-3) / 1e9,
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": None,
