@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the SAD disparity hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-gpu F]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-gpu F] [--weak]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
           --master-port P bench.py --gpus N --steps K --warmup W)
 
-Workload (BASELINE.json configs[2]/[3]): 1920x1080 synthetic grayscale pairs, block 9, Dmax 64.
-A "step" = one pass of the hot path over this rank's shard of the frame stream: F independent
-pairs (default 1024 = the length of config 4's frame stream, per GPU), device-resident (generated in HBM
-before the timed region), one batched launch on torch's current stream through the C ABI.
-Frames shard round-robin across ranks with no data-path collective (weak scaling); the two
-parameters are broadcast from rank 0 over RCCL.
+Workload (BASELINE.json configs[2]/[3]/[4]): 1920x1080 synthetic grayscale pairs, block 9, Dmax 64.
+A "step" = one pass of the hot path over this rank's shard of config 4's stream of 1024 independent
+pairs: frame i -> GPU i mod N, so a rank holds 1024 / N pairs (N = 1: all 1024; "scaling": "strong" --
+BASELINE config 4 is 1024 pairs IN TOTAL over 1/2/4/8 GPUs).  --weak keeps 1024 pairs per GPU instead;
+--frames-per-gpu sets the shard length directly.  The shard is device-resident (generated in HBM before
+the timed region), one batched launch on torch's current stream through the C ABI.  No data-path
+collective; the two parameters are broadcast from rank 0 over RCCL.
+
+Outside the timed headline, at N = 1: "host_fed" (sadhip_disparity_batch_u8 on frames in host memory,
+page-locked and pageable -- what a Go / C++ host calls; PCIe-inclusive, never `value`) and "pool"
+(sadhip_pool_batch_u8 over every visible device).
 
 Prints ONE JSON line on rank 0: metric = stereo pairs/s (whole job), plus ms/frame, the HBM
 roofline object for the disparity kernel, candidate evaluations/s, and the CPU baseline
@@ -107,12 +112,86 @@ def _time_reference_c(ctx, sha):
         return {"error": repr(e)}
 
 
+def _host_legs(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf):
+    """SURVEY 8(d) "separately: end-to-end incl. H2D + D2H" and 8(e) "(ii) host-fed": the same frames from HOST
+    memory through the entry points a Go / C++ host calls (examples/run.stream.go:46-62 prints the same per-frame
+    elapsed).  Bus-inclusive; reported beside the headline, never as it."""
+    import numpy as np
+    capi = sha.capi
+    frame = W * H
+    ref = out[:nf].cpu().numpy()                                  # the device-resident results of the timed launches
+    legs = {}
+    with capi.HostBuffer(3 * nf * frame) as hb:
+        blk = hb.view((3, nf, H, W))
+        blk[0] = Ls[:nf].cpu().numpy(); blk[1] = Rs[:nf].cpu().numpy()
+        lefts, rights, outs = [blk[0, i] for i in range(nf)], [blk[1, i] for i in range(nf)], [blk[2, i] for i in range(nf)]
+
+        def timed(fn, reps=3):
+            fn()                                                  # warm-up (allocates the group buffers)
+            best = None
+            for _ in range(reps):
+                blk[2] = 0
+                t0 = time.perf_counter()
+                fn()
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            return best, bool(np.array_equal(blk[2], ref))
+
+        dt, ok = timed(lambda: ctx.disparity_batch(lefts, rights, block, maxdisp, flags, outs=outs))
+        k_ms, t_ms = ctx.last_timing()
+        legs["host_fed"] = {
+            "value": nf / dt, "unit": "pairs/s", "frames": nf, "ms_per_frame": dt / nf * 1e3,
+            "pcie_gb_per_s": 3 * frame * nf / dt / 1e9, "pcie_h2d_gb_per_s": 2 * frame * nf / dt / 1e9,
+            "entry": "sadhip_disparity_batch_u8", "memory": "page-locked (sadhip_host_alloc), one contiguous block per plane",
+            "kernel_ms_per_frame": k_ms / nf, "matches_device_resident": ok,
+            "note": "groups of 8 frames per launch, one stream per direction (uploads / kernels / downloads chained by events), "
+                    "asynchronous linear copies; bound by the bus's host-to-device direction (4.15 MB per pair in, 2.07 MB out; "
+                    "tools/ubench/pcie_bw.hip: 55-57 GB/s one way, 47 + 47 with both directions busy)"}
+        # single synchronous call per pair from page-locked memory: the WebUI's shape (one pair per processDepthMap)
+        t0 = time.perf_counter()
+        for i in range(min(nf, 32)):
+            ctx.disparity(lefts[i], rights[i], block, maxdisp, flags, out=outs[i])
+        one = (time.perf_counter() - t0) / min(nf, 32)
+        k1, _ = ctx.last_timing()
+        legs["host_fed"]["single_call_ms"] = {"page_locked": one * 1e3, "kernel": k1}
+        # the same batch from pageable memory (Go heap memory is pageable: image.Gray.Pix)
+        npg = min(nf, 64)
+        pl = [np.array(blk[0, i]) for i in range(npg)]; pr = [np.array(blk[1, i]) for i in range(npg)]
+        po = [np.zeros((H, W), np.uint8) for _ in range(npg)]          # touched: no page faults inside the timed call
+        ctx.disparity_batch(pl, pr, block, maxdisp, flags, outs=po)          # warm-up over the same pages
+        t0 = time.perf_counter()
+        ctx.disparity_batch(pl, pr, block, maxdisp, flags, outs=po)
+        dtp = time.perf_counter() - t0
+        okp = all(np.array_equal(po[i], ref[i]) for i in range(npg))
+        t0 = time.perf_counter()
+        for i in range(min(npg, 16)):
+            ctx.disparity(pl[i], pr[i], block, maxdisp, flags, out=po[i])
+        onep = (time.perf_counter() - t0) / min(npg, 16)
+        legs["host_fed"]["pageable"] = {"value": npg / dtp, "unit": "pairs/s", "frames": npg, "pcie_gb_per_s": 3 * frame * npg / dtp / 1e9,
+                                        "matches_device_resident": okp,
+                                        "note": "2-D copies through the HIP runtime's own staging (the cgo shim's case)"}
+        legs["host_fed"]["single_call_ms"]["pageable"] = onep * 1e3
+        # the native pool over every visible device (frame i -> device i mod G), same page-locked frames
+        ndev = capi.device_count()
+        devices = [local] if ndev <= 1 else list(range(ndev))
+        with capi.Pool(devices, W, H) as pool:
+            dt, ok = timed(lambda: pool.batch(lefts, rights, block, maxdisp, flags, outs=outs))
+            k_sum, wall = pool.last_timing()
+        legs["pool"] = {"value": nf / dt, "unit": "pairs/s", "frames": nf, "devices": devices, "pcie_gb_per_s": 3 * frame * nf / dt / 1e9,
+                        "entry": "sadhip_pool_batch_u8", "memory": "page-locked (sadhip_host_alloc)", "kernel_ms_sum": k_sum,
+                        "matches_device_resident": ok,
+                        "note": "one context + host thread per device, frame i -> device i mod G; on a one-GPU box this is one context"}
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-gpu", type=int, default=1024)
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="pairs per GPU per step (default: 1024 / N, config 4's split; N = 1: 1024)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: 1024 pairs per GPU whatever N is")
+    ap.add_argument("--host-frames", type=int, default=256, help="frames of the host-fed / pool legs (N = 1 only; 0 = skip them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU baseline (default: every core this process may use)")
     ap.add_argument("--flags", type=int, default=0, help="sadhip flags (2 = force generic kernel)")
@@ -139,7 +218,13 @@ def main():
     # parameters: rank 0 decides, everyone else receives them (2 x int32 over RCCL/xGMI)
     block, maxdisp = sha.shard.broadcast_params(dist, rank, BLOCK, MAXDISP, cdev)
 
-    F = args.frames_per_gpu
+    STREAM = 1024                                                 # BASELINE config 4: 1024 independent pairs
+    if args.frames_per_gpu > 0:
+        F, scaling = args.frames_per_gpu, "weak"                  # a fixed shard per GPU
+    elif args.weak:
+        F, scaling = STREAM, "weak"
+    else:
+        F, scaling = (STREAM + world - 1) // world, "strong"      # config 4: the stream split over the GPUs (N = 1: all of it)
     seeds = sha.shard.frame_seeds(rank, world, F)                 # frame i -> GPU i mod G
     Ls, Rs = [], []
     for c in range(0, F, 16):                                     # generate in HBM, in chunks
@@ -208,11 +293,12 @@ def main():
         "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]/[3]: {W}x{H} synthetic pairs (splitmix64, seeds 1000+i), "
-                               f"block={block}, Dmax={maxdisp}; {F} device-resident pairs per GPU per step, "
-                               "frames sharded round-robin, params broadcast only",
+                               f"block={block}, Dmax={maxdisp}; {F} device-resident pairs per GPU per step"
+                               + (f" = BASELINE config 4's stream of {STREAM} pairs split over {world} GPU(s)" if scaling == "strong" else "")
+                               + ", frames sharded round-robin, params broadcast only",
                    "frames_per_gpu_per_step": F, "width": W, "height": H, "block": block, "maxdisp": maxdisp,
                    "kernel_kind": sha.capi.kernel_kind(W, H, block, maxdisp, args.flags)},
         "ms_per_frame": avg_launch_ms / F,
@@ -277,6 +363,12 @@ def main():
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
+    if world == 1 and args.host_frames > 0:
+        try:
+            res.update(_host_legs(sha, ctx, local, Ls, Rs, out, block, maxdisp, args.flags, min(args.host_frames, F)))
+        except Exception as e:                                    # side measurements never fail the headline
+            res["host_fed"] = {"error": repr(e)}
+
     if not args.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract)
         # the reference's own C (hardware/sad.c, compiled unmodified into oracle/_ref/ in the build
         # container) on its own fixed workload, next to the GPU running the same semantics: not the
@@ -313,7 +405,9 @@ def main():
         res["cpu_baseline"] = {
             "value": nn / wn, "unit": "pairs/s", "cores": ncpu, "kind": "port", "cpu_model": model, "host_logical_cpus": host_cpus,
             "sample": f"{nn} full {W}x{H} pairs (frame seeds 1000..{1000 + nn - 1} of this rank), literal restatement of "
-                      f"pkg/despair sad.go:55-94 in C, {ncpu} threads over output.go row bands, {wn:.2f} s wall = {wn * ncpu:.0f} CPU-seconds",
+                      f"pkg/despair sad.go:55-94 in C, {ncpu} threads over output.go row bands, {wn:.2f} s wall = {wn * ncpu:.0f} CPU-seconds"
+                      + ("" if args.cpu_threads else f"; {ncpu} = this tenant's share of the {host_cpus}-thread host -- the all-thread run was measured in round 2 "
+                                                     "(256 threads on the shared host) and is SLOWER: 3.1 against 3.7 pairs/s"),
             "single_thread": {"value": n1 / w1 if w1 > 0 else None, "unit": "pairs/s", "cores": 1,
                               "sample": f"{n1} full pair, same code, 1 thread, {w1:.2f} s"},
             "gpu_output_matches": ok}

@@ -42,7 +42,9 @@
 extern "C" {
 #endif
 
-#define SADHIP_ABI_VERSION 2   /* 2: flag validation, MIRROR_VERILOG, sadhip_last_kernel_kind, sadhip_pool_* */
+#define SADHIP_ABI_VERSION 3   /* 2: flag validation, MIRROR_VERILOG, sadhip_last_kernel_kind, sadhip_pool_*;
+                                * 3: sadhip_disparity_lr_u8 (left / right images of different sizes), sadhip_host_* (page-locked
+                                *    host memory), sadhip_plan_describe_batch */
 
 #if defined(__GNUC__)
 #define SADHIP_API __attribute__((visibility("default")))
@@ -53,7 +55,7 @@ extern "C" {
 /* status codes */
 #define SADHIP_OK               0
 #define SADHIP_ERR_NULL         1   /* a required pointer is NULL */
-#define SADHIP_ERR_DIMS         2   /* w <= 0 or h <= 0, or larger than the context capacity */
+#define SADHIP_ERR_DIMS         2   /* w <= 0 or h <= 0, larger than the context capacity, or a right image too small for the call */
 #define SADHIP_ERR_STRIDE       3   /* a row stride is smaller than w */
 #define SADHIP_ERR_BLOCK        4   /* block < 1 or block > SADHIP_MAX_BLOCK */
 #define SADHIP_ERR_MAXDISP      5   /* maxdisp < 1 (the reference divides by zero) or > SADHIP_MAX_MAXDISP */
@@ -123,10 +125,36 @@ SADHIP_API int sadhip_disparity_region_u8(sadhip_ctx* ctx,
                                int x0, int y0, int x1, int y1,
                                uint8_t* out_region);
 
+/* ---- left and right images of DIFFERENT sizes, host buffers (synchronous) ---------------------
+ * Every other disparity entry point takes ONE w x h: both images must hold at least w x h pixels (they
+ * read exactly w bytes of h rows of each).  The reference has no such rule: pkg/camera/output.go:134-162
+ * decodes left.png and right.png independently, the worker iterates over the LEFT image's rectangle and
+ * SumAbsoluteDifferences clamps the left window to left.Rect, walks the right window with the same
+ * extent and breaks where it leaves right.Rect.Max (sad.go:212-218,225-227,231-233).  This entry point
+ * is that contract: region [x0,x1) x [y0,y1) of the left image (image.Rect(0,0,lw,lh) for RunSad,
+ * InputChunk.Region for a worker chunk), out = (y1-y0) rows of (x1-x0) bytes, ostride apart.
+ *   right at least lw x lh:  the ordinary job on its top-left lw x lh part (no right pixel beyond it is ever
+ *                            addressed), column-wave kernel;
+ *   right smaller:           window terms whose right pixel does not exist are dropped, as the reference's
+ *                            breaks do (pixels whose whole right window is missing get SAD 0 at d = 0);
+ *                            generic kernel (sadhip_last_kernel_kind() == 0).  Hardware-mirror flags are
+ *                            rejected with SADHIP_ERR_DIMS there (those models have one image size).
+ * Only right pixels that exist are read from the caller's memory. */
+SADHIP_API int sadhip_disparity_lr_u8(sadhip_ctx* ctx,
+                           const uint8_t* left, int lw, int lh, int lstride,
+                           const uint8_t* right, int rw, int rh, int rstride,
+                           int block, int maxdisp, unsigned flags,
+                           int x0, int y0, int x1, int y1,
+                           uint8_t* out, int ostride);
+
 /* ---- batch of independent frames, host buffers (synchronous; pipelined inside) --------------
  * Replaces the streaming loop of examples/run.stream.go:30-59 / BASELINE config 4: n independent
  * pairs (any n >= 0), H2D / kernel / D2H double-buffered on the context's two streams; copies go
- * straight from / to the caller's buffers (2-D copies), nothing is retained after return. */
+ * straight from / to the caller's buffers (2-D copies), nothing is retained after return.
+ * When every frame of the batch lies in page-locked memory this library knows (sadhip_host_alloc /
+ * sadhip_host_register below), the batch runs as groups of frames per kernel launch with truly
+ * asynchronous linear copies (frames that follow each other in memory travel as one copy): the
+ * PCIe-bound rate of pkg/camera's frame stream instead of the runtime's pageable staging. */
 SADHIP_API int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
                               const uint8_t* const* lefts, const uint8_t* const* rights,
                               int w, int h, int lstride, int rstride,
@@ -194,6 +222,28 @@ SADHIP_API int sadhip_last_kernel_kind(void);
  * packed=<0|1> extra=<0|1> w16=<0|1> fl=<0|1> lds=<bytes>", into buf (NUL-terminated, truncated to cap).
  * Returns the number of passes, 0 when the generic kernel would run, -1 on invalid parameters. */
 SADHIP_API int sadhip_plan_describe(int w, int h, int block, int maxdisp, char* buf, int cap);
+
+/* The same for a batch of n frames ON THE CALLING THREAD'S CURRENT HIP DEVICE, with the launch geometry
+ * appended to every line: " tiles=<workgroups across a frame> strips=<strips per frame> rows=<output rows per
+ * strip> wg_per_cu=<resident workgroups of this kernel per CU> device=<1: asked from the runtime, 0: no device,
+ * one workgroup per CU assumed>".  Strip s of a frame computes the output rows [s*rows, min((s+1)*rows, h)):
+ * the seams the full-size parity tests put their literal-oracle rows on. */
+SADHIP_API int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, int n, char* buf, int cap);
+
+/* ---- page-locked host memory ---------------------------------------------------------------------
+ * The reference hands the worker Go heap memory (image.Gray.Pix); a cgo callee may not keep such
+ * pointers, so the host-buffer entry points copy from / to pageable memory through the HIP runtime's own
+ * staging (about half the PCIe rate, and the host thread is busy while it happens).  A capture pipeline
+ * (pkg/camera/serial.go fills a frame buffer per UART frame) or the C++ / Python host can keep its frames
+ * in page-locked memory instead: sadhip_host_alloc returns hipHostMalloc'ed memory usable from every
+ * device (a Go caller wraps it with unsafe.Slice as image.Gray.Pix -- C memory, not Go memory);
+ * sadhip_host_register page-locks memory the caller already owns (C / C++ hosts only: NEVER Go heap
+ * memory) until sadhip_host_unregister.  Every host-buffer entry point recognises pointers inside such
+ * ranges and then uses asynchronous linear copies; results are identical either way. */
+SADHIP_API int sadhip_host_alloc(size_t bytes, void** out);
+SADHIP_API int sadhip_host_free(void* p);
+SADHIP_API int sadhip_host_register(void* p, size_t bytes);
+SADHIP_API int sadhip_host_unregister(void* p);
 
 /* ---- multi-device pool (host buffers, synchronous) -------------------------------------------
  * Replaces, for a host with several GPUs, the streaming loop of examples/run.stream.go:30-59 at

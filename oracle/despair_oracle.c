@@ -76,9 +76,14 @@ ORACLE_API int oracle_sum_absolute_differences(
 /* raw != 0 stores bestDisparity itself (u8, for the hardware fixtures).     */
 /* Returns 0, or -1 on maxDisparity <= 0 (the reference panics there).       */
 /* ------------------------------------------------------------------------ */
-ORACLE_API int oracle_region_literal(
-    const uint8_t *left, const uint8_t *right, int w, int h,
-    int lstride, int rstride, int blockSize, int maxDisparity,
+/* Left and right image with their OWN sizes, as the reference's types allow  */
+/* (two *image.Gray; pkg/camera/output.go:134-162 decodes them independently): */
+/* the region and the left-edge skip rule refer to the LEFT image             */
+/* (sad.go:55-57,64-67), SumAbsoluteDifferences clamps / breaks per image.     */
+ORACLE_API int oracle_region_literal_lr(
+    const uint8_t *left, int lw, int lh, int lstride,
+    const uint8_t *right, int rw, int rh, int rstride,
+    int blockSize, int maxDisparity,
     int x0, int y0, int x1, int y1, uint8_t *out, int raw)
 {
     if (maxDisparity <= 0) return -1;
@@ -91,7 +96,7 @@ ORACLE_API int oracle_region_literal(
             for (int d = 0; d <= maxDisparity; d++) {    /* sad.go:62 */
                 if ((x0 + x) - d < 0) continue;          /* sad.go:64-67 */
                 int sad = oracle_sum_absolute_differences(
-                    left, w, h, lstride, right, w, h, rstride,
+                    left, lw, lh, lstride, right, rw, rh, rstride,
                     x0 + x, globalY, x0 + x - d, globalY, blockSize); /* :69-77 */
                 if (sad < minSAD) {                      /* sad.go:79 */
                     minSAD = sad;
@@ -104,6 +109,15 @@ ORACLE_API int oracle_region_literal(
         }
     }
     return 0;
+}
+
+ORACLE_API int oracle_region_literal(
+    const uint8_t *left, const uint8_t *right, int w, int h,
+    int lstride, int rstride, int blockSize, int maxDisparity,
+    int x0, int y0, int x1, int y1, uint8_t *out, int raw)
+{
+    return oracle_region_literal_lr(left, w, h, lstride, right, w, h, rstride,
+                                    blockSize, maxDisparity, x0, y0, x1, y1, out, raw);
 }
 
 /* ------------------------------------------------------------------------ */

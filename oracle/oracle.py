@@ -29,6 +29,7 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.oracle_sum_absolute_differences.restype = C.c_int
         _LIB.oracle_region_literal.restype = C.c_int
+        _LIB.oracle_region_literal_lr.restype = C.c_int
         _LIB.oracle_region_closed.restype = C.c_int
         _LIB.oracle_rows_literal_mt.restype = C.c_int
         _LIB.oracle_mirror_verilog_strip.restype = C.c_int
@@ -69,6 +70,21 @@ def _region(fn, left, right, block, maxdisp, region, raw):
 def disparity_literal(left, right, block, maxdisp, region=None, raw=False):
     """Literal restatement of sad.go:55-94 over region (x0,y0,x1,y1); region-local output."""
     return _region(lib().oracle_region_literal, left, right, block, maxdisp, region, raw)
+
+
+def disparity_literal_lr(left, right, block, maxdisp, region=None, raw=False):
+    """The same literal loops for a right image of ANY size (sad.go:212-218,225-227,231-233 clamp / break per
+    image); region of the left image, region-local output."""
+    _chk(left), _chk(right)
+    lh, lw = left.shape
+    rh, rw = right.shape
+    x0, y0, x1, y1 = region if region is not None else (0, 0, lw, lh)
+    out = np.zeros((max(y1 - y0, 0), max(x1 - x0, 0)), np.uint8)
+    rc = lib().oracle_region_literal_lr(_p(left), lw, lh, left.strides[0], _p(right), rw, rh, right.strides[0],
+                                        block, maxdisp, x0, y0, x1, y1, _p(out), 1 if raw else 0)
+    if rc != 0:
+        raise ZeroDivisionError("MaxDisparity <= 0 (the reference panics: integer divide by zero, sad.go:92)")
+    return out
 
 
 def disparity_closed(left, right, block, maxdisp, region=None, raw=False):

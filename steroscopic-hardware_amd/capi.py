@@ -25,7 +25,7 @@ FLAG_MIRROR_SADC = 4
 FLAG_MIRROR_TESTPY = 8
 FLAG_MIRROR_VERILOG = 16
 KIND_GENERIC, KIND_COLWAVE, KIND_MIRROR_SADC, KIND_MIRROR_TESTPY, KIND_MIRROR_VERILOG = range(5)
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_BLOCK = 255
 MAX_MAXDISP = 4096
 
@@ -45,6 +45,8 @@ SYMBOLS = {
                                       C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int]),
     "sadhip_disparity_region_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sadhip_disparity_lr_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "sadhip_disparity_batch_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
                                             C.POINTER(C.c_void_p), C.c_int]),
@@ -60,6 +62,11 @@ SYMBOLS = {
     "sadhip_kernel_kind": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
     "sadhip_last_kernel_kind": (C.c_int, []),
     "sadhip_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "sadhip_plan_describe_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "sadhip_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "sadhip_host_free": (C.c_int, [C.c_void_p]),
+    "sadhip_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "sadhip_host_unregister": (C.c_int, [C.c_void_p]),
     "sadhip_pool_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sadhip_pool_destroy": (C.c_int, [C.c_void_p]),
     "sadhip_pool_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -163,6 +170,60 @@ def plan_describe(w, h, block, maxdisp):
     return [{k: int(v) for k, v in (f.split("=") for f in line.split())} for line in buf.value.decode().splitlines()]
 
 
+def plan_describe_batch(w, h, block, maxdisp, n):
+    """plan_describe for a batch of n frames on the current HIP device, with the launch geometry of every
+    pass: tiles, strips (per frame), rows (output rows per strip), wg_per_cu, device (1 = occupancy asked from
+    the runtime).  Strip s of a frame computes output rows [s*rows, min((s+1)*rows, h))."""
+    buf = C.create_string_buffer(16384)
+    k = lib().sadhip_plan_describe_batch(w, h, block, maxdisp, n, buf, len(buf))
+    if k < 0:
+        raise SadHipError(ERR_ARG, "invalid parameters")
+    return [{k: int(v) for k, v in (f.split("=") for f in line.split())} for line in buf.value.decode().splitlines()]
+
+
+class HostBuffer:
+    """Page-locked host memory from sadhip_host_alloc, exposed as a uint8 numpy array (``.array``, any shape
+    with the same number of bytes via ``.view(shape)``).  Frames kept in it travel with asynchronous linear
+    copies (include/sadhip.h "page-locked host memory").  close() frees it: do not use views afterwards."""
+
+    def __init__(self, nbytes):
+        self._p = C.c_void_p()
+        _check(lib().sadhip_host_alloc(nbytes, C.byref(self._p)))
+        self.nbytes = nbytes
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self._p.value))
+
+    def view(self, shape):
+        return self.array[:int(np.prod(shape))].reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            _check(lib().sadhip_host_free(self._p))
+            self._p = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_register(a):
+    """Page-locks the memory of a C-contiguous numpy array (sadhip_host_register); pair with host_unregister."""
+    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
+    _check(lib().sadhip_host_register(a.ctypes.data, a.nbytes))
+
+
+def host_unregister(a):
+    _check(lib().sadhip_host_unregister(a.ctypes.data))
+
+
 def _img(a, name):
     if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.ndim != 2 or a.strides[1] != 1 or a.strides[0] < 0:
         raise TypeError(f"{name}: expected a 2-D uint8 numpy array with unit column stride")
@@ -218,6 +279,20 @@ class Context:
         _check(lib().sadhip_disparity_region_u8(self._h, left.ctypes.data, right.ctypes.data, w, h,
                                                 left.strides[0], right.strides[0], block, maxdisp, flags,
                                                 x0, y0, x1, y1, out.ctypes.data if out.size else np.empty(1, np.uint8).ctypes.data))
+        return out
+
+    def disparity_lr(self, left, right, block, maxdisp, region=None, flags=0):
+        """Left and right images with their OWN sizes (sadhip_disparity_lr_u8): the reference's behaviour for
+        independently decoded pictures (sad.go:212-218,225-227,231-233).  Region of the left image; region-local output."""
+        _img(left, "left"), _img(right, "right")
+        lh, lw = left.shape
+        rh, rw = right.shape
+        x0, y0, x1, y1 = region if region is not None else (0, 0, lw, lh)
+        out = np.empty((max(y1 - y0, 0), max(x1 - x0, 0)), np.uint8)
+        _check(lib().sadhip_disparity_lr_u8(self._h, left.ctypes.data, lw, lh, left.strides[0],
+                                            right.ctypes.data, rw, rh, right.strides[0], block, maxdisp, flags,
+                                            x0, y0, x1, y1, out.ctypes.data if out.size else np.empty(1, np.uint8).ctypes.data,
+                                            max(x1 - x0, 1)))
         return out
 
     def disparity_batch(self, lefts, rights, block, maxdisp, flags=0, outs=None):

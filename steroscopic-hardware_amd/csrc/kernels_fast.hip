@@ -1160,6 +1160,8 @@ inline size_t plan_lds_bytes(const Plan& pl, int h, int maxdisp)
 }
 struct Pass { Plan pl; int dbase; };              // candidates [dbase, dbase + nw*nd (+1)) of the job
 struct PassIo { int dbase; const unsigned* kin; unsigned* kout; int kw; };
+// launch geometry of one pass, as launch_t would launch it on the current device (sadhip_plan_describe_batch)
+struct PassGeom { int tiles = 0, strips = 0, rows = 0, per_cu = 0; bool device = false; };
 
 // Tuning aids.  The product build (libsadhip.so) reads NO environment variable: env_int() is the
 // constant default there, so a stray variable in the host process cannot change a plan.  The
@@ -1365,18 +1367,22 @@ static int cu_count()
   return cus;
 }
 
+// workgroups of `kernel` a CU holds (registers, LDS, waves), asked from the runtime once per instantiation, shape and
+// thread; *asked (optional) = the runtime answered (false: no usable device, one workgroup per CU assumed)
 template <typename Kernel>
-static int wgs_per_cu(Kernel kernel, int threads, size_t lds)
+static int wgs_per_cu(Kernel kernel, int threads, size_t lds, bool* asked = nullptr)
 {
-  struct Entry { int dev, threads; size_t lds; int n; };
+  struct Entry { int dev, threads; size_t lds; int n; bool asked; };
   thread_local std::vector<Entry> cache;                        // per kernel instantiation (template) and thread
   int dev = 0;
-  (void)hipGetDevice(&dev);
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); if (asked) *asked = false; return 1; }
   for (const Entry& e : cache)
-    if (e.dev == dev && e.threads == threads && e.lds == lds) return e.n;
+    if (e.dev == dev && e.threads == threads && e.lds == lds) { if (asked) *asked = e.asked; return e.n; }
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
-  cache.push_back(Entry{dev, threads, lds, n});
+  bool ok = true;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; ok = false; }
+  cache.push_back(Entry{dev, threads, lds, n, ok});
+  if (asked) *asked = ok;
   return n;
 }
 
@@ -1385,8 +1391,9 @@ static int wgs_per_cu(Kernel kernel, int threads, size_t lds)
 // is routed to the generic kernel at PLANNING time and never by a silent fallback after a failure.
 // part: 0 = every tile of the job; 1 = only the tiles before the first one that holds the image's last two
 // columns (the triple-column form, TR); 2 = only the tiles from that one on (the plain form next to it).
+// geom (optional): fill in the launch geometry and return without launching.
 template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false, bool FL = false, bool TR = false>
-hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, int part = 0)
+hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, int part = 0, PassGeom* geom = nullptr)
 {
   using K = Cw<P, ND, H, PK, W16, FL, TR>;
   static_assert(!TR || !FL, "");
@@ -1441,6 +1448,8 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   // shortest strip: 8 rows (single small frames: 640x480 28.8 -> 26.7 us, 1280x720 B9 47.1 -> 38.5; no change at 1080p)
   const int min_rows = env_int("SADHIP_TUNE_MINROWS", 8);
   long nstrips;
+  bool asked = false;
+  const int per_cu = wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL, TR>, 64 * pl.nw, lds, &asked);
   if (env_int("SADHIP_TUNE_LEGACY_STRIPS", 0)) {                // round 2's constants, for comparison
     const long want = env_int("SADHIP_TUNE_WGS", P == 4 ? 512 : 256);
     const long rows_target = env_int("SADHIP_TUNE_ROWS", 48 * H), wg_max = env_int("SADHIP_TUNE_WGMAX", 4096);
@@ -1449,16 +1458,17 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   } else if (env_int("SADHIP_TUNE_STRIPS", 0) > 0) {
     nstrips = env_int("SADHIP_TUNE_STRIPS", 0);
   } else {
-    nstrips = choose_strips(base, rows, 2 * H, cu_count(), wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL, TR>, 64 * pl.nw, lds), min_rows);
+    nstrips = choose_strips(base, rows, 2 * H, cu_count(), per_cu, min_rows);
   }
   const long max_strips = (rows + min_rows - 1) / min_rows;
   if (nstrips > max_strips) nstrips = max_strips;
   if (nstrips < 1) nstrips = 1;
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
+  if (geom) { geom->tiles = ntiles; geom->strips = (int)nstrips; geom->rows = a.th; geom->per_cu = per_cu; geom->device = asked; return hipSuccess; }
   if (env_int("SADHIP_TUNE_VERBOSE", 0))
     fprintf(stderr, "sadhip: P%d ND%d H%d nw%d: %ld strips of %d rows x %ld workgroups per layer, %d per CU, lds %zu\n", P, ND, H, pl.nw, nstrips, a.th,
-            base, wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL, TR>, 64 * pl.nw, lds), lds);
+            base, per_cu, lds);
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     CwArgs aa = a;
     aa.j.n = (j.n - f0 < 32768) ? j.n - f0 : 32768;
@@ -1518,11 +1528,14 @@ static bool passes_launchable(const Job& j, const std::vector<Pass>& passes);
 bool fast_supported(const Job& j)
 {
   if (j.w < 1 || j.h < 1) return false;
+  if ((j.rw > 0 && j.rw < j.w) || (j.rh > 0 && j.rh < j.h)) return false;   // smaller right image: dropped terms, generic kernel only
   const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2);   // BlockSize 2..31
   return !passes.empty() && passes_launchable(j, passes);
 }
 
-int describe_fast(const Job& j, char* buf, int cap)
+static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry = false, PassGeom* geom = nullptr);
+
+int describe_fast(const Job& j, char* buf, int cap, bool geometry)
 {
   if (buf && cap > 0) buf[0] = 0;
   if (!fast_supported(j)) return 0;
@@ -1534,50 +1547,57 @@ int describe_fast(const Job& j, char* buf, int cap)
     const int next = k + 1 < passes.size() ? passes[k + 1].dbase : j.maxdisp + 1;
     const size_t lds = plan_lds_bytes(pl, h, j.maxdisp);
     if (buf && at < cap)
-      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d fl=%d lds=%zu\n",
+      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d fl=%d lds=%zu",
                      passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, (int)pl.fl, lds);
+    if (geometry) {
+      PassGeom g;
+      if (launch_pass(j, pl, PassIo{passes[k].dbase, nullptr, nullptr, j.x1 - j.x0}, nullptr, false, &g) != hipSuccess) return -1;
+      if (buf && at < cap)
+        at += snprintf(buf + at, (size_t)(cap - at), " tiles=%d strips=%d rows=%d wg_per_cu=%d device=%d", g.tiles, g.strips, g.rows, g.per_cu, (int)g.device);
+    }
+    if (buf && at < cap) at += snprintf(buf + at, (size_t)(cap - at), "\n");
   }
   return (int)passes.size();
 }
 
-static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry = false)
+static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, PassGeom* geom)
 {
   const int h = j.block / 2;
 #ifdef SADHIP_TUNING            // the float variant is an experiment (slower than the packed kernels): diagnostics build only
-#define SADHIP_FL(HH) if (pl.fl && h == HH) return launch_t<8, 8, HH, false, 1024, false, true>(j, pl, io, s, dry)
+#define SADHIP_FL(HH) if (pl.fl && h == HH) return launch_t<8, 8, HH, false, 1024, false, true>(j, pl, io, s, dry, 0, geom)
   SADHIP_FL(4); SADHIP_FL(5); SADHIP_FL(6); SADHIP_FL(7);
 #endif
   if (pl.fl) return hipErrorInvalidValue;
 #ifdef SADHIP_EXPERIMENT        // resource-usage experiments: only the instantiations under study (seconds to compile)
-  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry);
-  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry);
-  if (pl.w16 && !pl.pk && h == 15) return launch_t<8, 8, 15, false, 1024, true>(j, pl, io, s, dry);
-  if (pl.p == 8 && pl.nd == 8 && h == 7 && pl.pk) return launch_t<8, 8, 7, true>(j, pl, io, s, dry);
-  if (pl.p == 8 && pl.nd == 8 && h == 5 && !pl.pk) return launch_t<8, 8, 5, false, 1024>(j, pl, io, s, dry);
+  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry, 0, geom);
+  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry, 0, geom);
+  if (pl.w16 && !pl.pk && h == 15) return launch_t<8, 8, 15, false, 1024, true>(j, pl, io, s, dry, 0, geom);
+  if (pl.p == 8 && pl.nd == 8 && h == 7 && pl.pk) return launch_t<8, 8, 7, true>(j, pl, io, s, dry, 0, geom);
+  if (pl.p == 8 && pl.nd == 8 && h == 5 && !pl.pk) return launch_t<8, 8, 5, false, 1024>(j, pl, io, s, dry, 0, geom);
   if (pl.p == 4 && pl.nd == 16 && h == 4 && pl.pk) {
     const int trmode = kTripleColumns ? env_int("SADHIP_TUNE_TRMODE", 2) : 0;
-    if (trmode == 0 || (trmode == 1 && !dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, 16, 4, true>(j, pl, io, s, dry);
-    if (trmode == 2) return launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 0);
-    const hipError_t e1 = launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1);
-    return e1 != hipSuccess ? e1 : launch_t<4, 16, 4, true>(j, pl, io, s, dry, 2);
+    if (trmode == 0 || (trmode == 1 && !dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, 16, 4, true>(j, pl, io, s, dry, 0, geom);
+    if (trmode == 2) return launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 0, geom);
+    const hipError_t e1 = launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1, geom);
+    return e1 != hipSuccess ? e1 : launch_t<4, 16, 4, true>(j, pl, io, s, dry, 2, geom);
   }
-  if (pl.p == 4 && pl.nd == 16 && h == 7 && pl.pk) return launch_t<4, 16, 7, true>(j, pl, io, s, dry);
+  if (pl.p == 4 && pl.nd == 16 && h == 7 && pl.pk) return launch_t<4, 16, 7, true>(j, pl, io, s, dry, 0, geom);
   return hipErrorInvalidValue;
 #else
-  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry);
-  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry);   // 128-VGPR build: two workgroups per CU
-#define SADHIP_W16U(HH) if (pl.w16 && !pl.pk && h == HH) return launch_t<8, 8, HH, false, 1024, true>(j, pl, io, s, dry)
+  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry, 0, geom);
+  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry, 0, geom);   // 128-VGPR build: two workgroups per CU
+#define SADHIP_W16U(HH) if (pl.w16 && !pl.pk && h == HH) return launch_t<8, 8, HH, false, 1024, true>(j, pl, io, s, dry, 0, geom)
   SADHIP_W16U(9); SADHIP_W16U(10); SADHIP_W16U(11); SADHIP_W16U(12); SADHIP_W16U(13); SADHIP_W16U(14); SADHIP_W16U(15);
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
-  if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s, dry)
+  if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s, dry, 0, geom)
   // BlockSize 9: triple-column form for the tiles left of the image's last two columns, plain form for the rest
 #define SADHIP_B9(NDD) \
   if (pl.p == 4 && pl.nd == NDD && h == 4 && pl.pk) { \
     const int trmode = kTripleColumns ? env_int("SADHIP_TUNE_TRMODE", 2) : 0;   /* 0 plain, 1 two launches split by tile, 2 one kernel that picks per workgroup */ \
-    if (trmode == 0 || (trmode == 1 && !dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, NDD, 4, true>(j, pl, io, s, dry); \
-    if (trmode == 2) return launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 0); \
-    const hipError_t e1 = launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1); \
-    return e1 != hipSuccess ? e1 : launch_t<4, NDD, 4, true>(j, pl, io, s, dry, 2); \
+    if (trmode == 0 || (trmode == 1 && !dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, NDD, 4, true>(j, pl, io, s, dry, 0, geom); \
+    if (trmode == 2) return launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 0, geom); \
+    const hipError_t e1 = launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1, geom); \
+    return e1 != hipSuccess ? e1 : launch_t<4, NDD, 4, true>(j, pl, io, s, dry, 2, geom); \
   }
 #define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_B9(NDD)
 #define SADHIP_P8(NDD) SADHIP_CASE(8, NDD, 5, true); SADHIP_CASE(8, NDD, 6, true); SADHIP_CASE(8, NDD, 7, true)
@@ -1592,11 +1612,11 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   // unpacked (window SAD does not fit 16 bits, or forced for comparison)
 #define SADHIP_U(HH, NDD) \
   if (pl.p == 8 && pl.nd == NDD && h == HH && !pl.pk) \
-    return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, io, s, dry) : launch_t<8, NDD, HH, false, 1024>(j, pl, io, s, dry)
+    return (64 * pl.nw <= 512 && env_int("SADHIP_TUNE_WB", 512) == 512) ? launch_t<8, NDD, HH, false, 512>(j, pl, io, s, dry, 0, geom) : launch_t<8, NDD, HH, false, 1024>(j, pl, io, s, dry, 0, geom)
   SADHIP_U(8, 4); SADHIP_U(8, 8);
   SADHIP_U(7, 4); SADHIP_U(7, 8); SADHIP_U(6, 4); SADHIP_U(6, 8);   // D without an exact packed plan
   SADHIP_U(5, 4); SADHIP_U(5, 8); SADHIP_U(4, 4); SADHIP_U(4, 8); SADHIP_U(3, 4); SADHIP_U(3, 8);   // narrow frames
-#define SADHIP_UH(HH) SADHIP_U(HH, 4); if (pl.p == 8 && pl.nd == 8 && h == HH && !pl.pk) return launch_t<8, 8, HH, false, 512>(j, pl, io, s, dry)
+#define SADHIP_UH(HH) SADHIP_U(HH, 4); if (pl.p == 8 && pl.nd == 8 && h == HH && !pl.pk) return launch_t<8, 8, HH, false, 512>(j, pl, io, s, dry, 0, geom)
   SADHIP_UH(9); SADHIP_UH(10); SADHIP_UH(11); SADHIP_UH(12); SADHIP_UH(13); SADHIP_UH(14); SADHIP_UH(15);   // BlockSize 18..31: two-lane halos
 #undef SADHIP_CASE
   return hipErrorInvalidValue;

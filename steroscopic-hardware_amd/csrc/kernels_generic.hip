@@ -31,15 +31,19 @@ k_disparity_generic(Job j)
   const int wy0 = max(y - hs, 0), wy1 = min(y + hs + 1, j.h);   // sad.go:212-213
   const int wx0 = max(x - hs, 0), wx1 = min(x + hs + 1, j.w);   // sad.go:214-215
   const int dmax = min(j.maxdisp, max(0, x - hs));              // sad.go:64-67 + :217-218 folded
+  // a right image smaller than the left one: rows >= rh and right columns >= rw end the walk (sad.go:225-227,231-233)
+  const int ry1 = j.rh > 0 ? min(wy1, j.rh) : wy1;
+  const int rwid = j.rw > 0 ? j.rw : j.w;
 
   unsigned best_sad = 0xffffffffu;
   int best = 0;
   for (int d = 0; d <= dmax; ++d) {                             // sad.go:62
     unsigned sad = 0;
-    for (int yy = wy0; yy < wy1; ++yy) {                        // sad.go:224
+    const int rx1 = min(wx1, rwid + d);                         // right column xx - d < rw
+    for (int yy = wy0; yy < ry1; ++yy) {                        // sad.go:224-227
       const uint8_t* lp = L + (size_t)(yy - j.row0) * j.lstride;
       const uint8_t* rp = R + (size_t)(yy - j.row0) * j.rstride - d;
-      for (int xx = wx0; xx < wx1; ++xx) {                      // sad.go:230
+      for (int xx = wx0; xx < rx1; ++xx) {                      // sad.go:230-233
         int diff = (int)lp[xx] - (int)rp[xx];                   // sad.go:234-235
         sad += (unsigned)(diff < 0 ? -diff : diff);             // sad.go:236-239
       }

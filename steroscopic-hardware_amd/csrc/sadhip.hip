@@ -14,6 +14,8 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
+#include <algorithm>
 #include <thread>
 #include <vector>
 
@@ -74,6 +76,90 @@ extern "C" int sadhip_device_count(int* count)
 }
 
 // ------------------------------------------------------------------------------------------
+// page-locked host memory this library knows about (sadhip_host_alloc / sadhip_host_register)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct PinnedRange { uintptr_t lo, hi; bool owned; };          // [lo, hi); owned: hipHostMalloc'ed here
+std::shared_mutex g_pin_mu;
+std::vector<PinnedRange> g_pins;                               // sorted by lo, disjoint
+
+// [p, p + bytes) lies inside one known range
+bool is_pinned(const void* p, size_t bytes)
+{
+  const uintptr_t a = (uintptr_t)p;
+  std::shared_lock<std::shared_mutex> lk(g_pin_mu);
+  auto it = std::upper_bound(g_pins.begin(), g_pins.end(), a, [](uintptr_t v, const PinnedRange& r) { return v < r.lo; });
+  if (it == g_pins.begin()) return false;
+  --it;
+  return a >= it->lo && a + bytes <= it->hi;
+}
+
+void pin_insert(void* p, size_t bytes, bool owned)
+{
+  const PinnedRange r{(uintptr_t)p, (uintptr_t)p + bytes, owned};
+  std::unique_lock<std::shared_mutex> lk(g_pin_mu);
+  g_pins.insert(std::upper_bound(g_pins.begin(), g_pins.end(), r.lo, [](uintptr_t v, const PinnedRange& q) { return v < q.lo; }), r);
+}
+
+// removes the range that STARTS at p; false when there is none of that kind
+bool pin_remove(void* p, bool owned)
+{
+  std::unique_lock<std::shared_mutex> lk(g_pin_mu);
+  for (auto it = g_pins.begin(); it != g_pins.end(); ++it)
+    if (it->lo == (uintptr_t)p && it->owned == owned) { g_pins.erase(it); return true; }
+  return false;
+}
+}  // namespace
+
+extern "C" int sadhip_host_alloc(size_t bytes, void** out)
+{
+  if (!out) return fail(SADHIP_ERR_NULL, "out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return fail(SADHIP_ERR_ARG, "bytes=0");
+  void* p = nullptr;
+  const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);    // usable from every device (the pool)
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(e == hipErrorOutOfMemory ? SADHIP_ERR_NOMEM : (e == hipErrorNoDevice ? SADHIP_ERR_NO_DEVICE : SADHIP_ERR_HIP),
+                "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  }
+  try { pin_insert(p, bytes, true); }
+  catch (const std::bad_alloc&) { (void)hipHostFree(p); return fail(SADHIP_ERR_NOMEM, "registry allocation failed"); }
+  *out = p;
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_host_free(void* p)
+{
+  if (!p) return fail(SADHIP_ERR_NULL, "p is NULL");
+  if (!pin_remove(p, true)) return fail(SADHIP_ERR_ARG, "%p was not returned by sadhip_host_alloc", p);
+  HIPTRY(hipHostFree(p));
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_host_register(void* p, size_t bytes)
+{
+  if (!p) return fail(SADHIP_ERR_NULL, "p is NULL");
+  if (bytes == 0) return fail(SADHIP_ERR_ARG, "bytes=0");
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(e == hipErrorNoDevice ? SADHIP_ERR_NO_DEVICE : SADHIP_ERR_HIP, "hipHostRegister(%p, %zu): %s", p, bytes, hipGetErrorString(e));
+  }
+  try { pin_insert(p, bytes, false); }
+  catch (const std::bad_alloc&) { (void)hipHostUnregister(p); return fail(SADHIP_ERR_NOMEM, "registry allocation failed"); }
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_host_unregister(void* p)
+{
+  if (!p) return fail(SADHIP_ERR_NULL, "p is NULL");
+  if (!pin_remove(p, false)) return fail(SADHIP_ERR_ARG, "%p was not registered with sadhip_host_register", p);
+  HIPTRY(hipHostUnregister(p));
+  return SADHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -92,6 +178,19 @@ struct sadhip_ctx {
   size_t plane = 0;            // bytes per staging plane
   static constexpr int kSlots = 2;
   Slot slot[kSlots];
+  // Batches whose frames all lie in page-locked memory (sadhip_host_*) run through these instead: kGroup frames per
+  // kernel launch, asynchronous linear copies, and ONE STREAM PER DIRECTION -- uploads, kernels and downloads each have
+  // their own stream, chained by events per slot.  (Uploads and downloads issued on one stream share a DMA engine and
+  // serialise: 36 GB/s host-to-device; a stream per direction reaches what tools/ubench/pcie_bw.hip measures for the
+  // bus with both directions busy, 47 + 47 GB/s.)  Allocated on first use: kGroupSlots x 3 x kGroup planes.
+  static constexpr int kGroup = 8, kGroupSlots = 4;
+  struct GroupSlot {
+    uint8_t *dL = nullptr, *dR = nullptr, *dO = nullptr;
+    hipEvent_t up = nullptr, k0 = nullptr, k1 = nullptr, down = nullptr;     // uploaded / kernel begin, end / downloaded
+  };
+  GroupSlot grp[kGroupSlots];
+  hipStream_t s_up = nullptr, s_kern = nullptr, s_down = nullptr;
+  bool grp_ready = false;
   // scratch for sad_windows / gray (grown on demand)
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* h_scratch = nullptr; size_t h_scratch_bytes = 0;
@@ -123,10 +222,13 @@ static int ensure_scratch(sadhip_ctx* c, size_t dbytes, size_t hbytes)
   return SADHIP_OK;
 }
 
+static void destroy_groups(sadhip_ctx* c);
+
 static void destroy_ctx(sadhip_ctx* c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  destroy_groups(c);
   for (auto& s : c->slot) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     if (s.hL) (void)hipHostFree(s.hL);
@@ -142,6 +244,45 @@ static void destroy_ctx(sadhip_ctx* c)
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->h_scratch) (void)hipHostFree(c->h_scratch);
   delete c;
+}
+
+static void destroy_groups(sadhip_ctx* c)
+{
+  for (hipStream_t st : {c->s_up, c->s_kern, c->s_down}) if (st) (void)hipStreamSynchronize(st);
+  for (auto& g : c->grp) {
+    if (g.dL) (void)hipFree(g.dL);
+    if (g.dR) (void)hipFree(g.dR);
+    if (g.dO) (void)hipFree(g.dO);
+    for (hipEvent_t e : {g.up, g.k0, g.k1, g.down}) if (e) (void)hipEventDestroy(e);
+    g = sadhip_ctx::GroupSlot{};
+  }
+  for (hipStream_t* st : {&c->s_up, &c->s_kern, &c->s_down}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
+  c->grp_ready = false;
+}
+
+static int ensure_groups(sadhip_ctx* c)
+{
+  if (c->grp_ready) return SADHIP_OK;
+  hipError_t e = hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_kern, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking);
+  for (auto& g : c->grp) {
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g.up, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g.down, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&g.k0);
+    if (e == hipSuccess) e = hipEventCreate(&g.k1);
+    if (e == hipSuccess) e = hipMalloc((void**)&g.dL, c->plane * sadhip_ctx::kGroup);
+    if (e == hipSuccess) e = hipMalloc((void**)&g.dR, c->plane * sadhip_ctx::kGroup);
+    if (e == hipSuccess) e = hipMalloc((void**)&g.dO, c->plane * sadhip_ctx::kGroup);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    destroy_groups(c);
+    return fail(e == hipErrorOutOfMemory ? SADHIP_ERR_NOMEM : SADHIP_ERR_HIP, "group buffers (%d x %d x %zu B): %s",
+                sadhip_ctx::kGroupSlots, sadhip_ctx::kGroup, c->plane, hipGetErrorString(e));
+  }
+  c->grp_ready = true;
+  return SADHIP_OK;
 }
 
 extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch, sadhip_ctx** out)
@@ -239,7 +380,16 @@ extern "C" int sadhip_plan_describe(int w, int h, int block, int maxdisp, char* 
   if (check_params(w, h, w, w, block, maxdisp) != SADHIP_OK) return -1;
   Job j{}; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp; j.n = 1;
   j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.lstride = j.rstride = j.ostride = w;
-  return describe_fast(j, buf, cap);
+  return describe_fast(j, buf, cap, false);
+}
+
+extern "C" int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, int n, char* buf, int cap)
+{
+  if (buf && cap > 0) buf[0] = 0;
+  if (n < 1 || check_params(w, h, w, w, block, maxdisp) != SADHIP_OK) return -1;
+  Job j{}; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp; j.n = n;
+  j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.lstride = j.rstride = j.ostride = w;
+  return describe_fast(j, buf, cap, true);
 }
 
 extern "C" int sadhip_last_kernel_kind(void) { return last_launch_kind(); }
@@ -274,18 +424,35 @@ using clk = std::chrono::steady_clock;
 // row pitch of the staging planes for a w-wide frame (<= the context's allocation pitch)
 static inline size_t pitch_for(int w) { return align_up((size_t)w, 256); }
 
+// rw, rh: the part of the right image that exists (<= w, h; == w, h unless the caller's right image is the smaller
+// one, sadhip_disparity_lr_u8): only that part is read from the caller's memory.
 static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint8_t* right,
                          int w, int h, int lstride, int rstride, int block, int maxdisp, unsigned flags,
-                         int x0, int y0, int x1, int y1, int band0, int band1)
+                         int x0, int y0, int x1, int y1, int band0, int band1, int rw = 0, int rh = 0)
 {
   const size_t pitch = pitch_for(w);
   const bool direct = !c->pinned_staging;   // default: 2-D copies straight from / to the caller's memory
-  if (direct) {
+  if (rw <= 0 || rw > w) rw = w;
+  if (rh <= 0 || rh > h) rh = h;
+  const int rband1 = band1 < rh ? band1 : rh;             // right rows [band0, rband1) exist
+  // Page-locked inputs this library knows (sadhip_host_*): one asynchronous linear copy per image, the device rows
+  // keep the caller's stride (the runtime stages nothing and the host thread does not wait for the bus).
+  size_t dl = pitch, dr = pitch;                           // device row strides
+  const size_t lbytes = (size_t)(band1 - band0 - 1) * lstride + w;
+  const size_t rbytes = rband1 > band0 ? (size_t)(rband1 - band0 - 1) * rstride + rw : 0;
+  const bool pinned = direct && (size_t)lstride * (band1 - band0) <= c->plane && (size_t)rstride * (band1 - band0) <= c->plane &&
+                      is_pinned(left + (size_t)band0 * lstride, lbytes) && (rbytes == 0 || is_pinned(right + (size_t)band0 * rstride, rbytes));
+  if (pinned) {
+    dl = (size_t)lstride; dr = (size_t)rstride;
+    HIPTRY(hipMemcpyAsync(s.dL, left + (size_t)band0 * lstride, lbytes, hipMemcpyHostToDevice, s.stream));
+    if (rbytes) HIPTRY(hipMemcpyAsync(s.dR, right + (size_t)band0 * rstride, rbytes, hipMemcpyHostToDevice, s.stream));
+  } else if (direct) {
     HIPTRY(hipMemcpy2DAsync(s.dL, pitch, left + (size_t)band0 * lstride, lstride, w, band1 - band0, hipMemcpyHostToDevice, s.stream));
-    HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, w, band1 - band0, hipMemcpyHostToDevice, s.stream));
+    if (rband1 > band0)
+      HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, rw, rband1 - band0, hipMemcpyHostToDevice, s.stream));
   } else {
   stage_rows(s.hL, pitch, left, lstride, w, band0, band1);
-  stage_rows(s.hR, pitch, right, rstride, w, band0, band1);
+  stage_rows(s.hR, pitch, right, rstride, rw, band0, rband1);
   const size_t bytes = (size_t)(band1 - band0) * pitch;
   HIPTRY(hipMemcpyAsync(s.dL, s.hL, bytes, hipMemcpyHostToDevice, s.stream));
   HIPTRY(hipMemcpyAsync(s.dR, s.hR, bytes, hipMemcpyHostToDevice, s.stream));
@@ -293,8 +460,9 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
   Job j{};
   j.left = s.dL; j.right = s.dR; j.out = s.dO;
   j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = c->plane;
-  j.lstride = j.rstride = j.ostride = (int)pitch;
+  j.lstride = (int)dl; j.rstride = (int)dr; j.ostride = (int)pitch;
   j.n = 1; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
+  j.rw = rw < w ? rw : 0; j.rh = rh < h ? rh : 0;
   j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1;
   j.ox = 0; j.oy = y0;            // staging output: row 0 = image row y0, full-width rows
   j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0;
@@ -351,6 +519,45 @@ extern "C" int sadhip_disparity_region_u8(sadhip_ctx* ctx, const uint8_t* left, 
   return SADHIP_OK;
 }
 
+// Left and right images with their own sizes (pkg/camera/output.go decodes the two PNGs independently).
+// A right image at least as large as the left one is the ordinary job on its top-left lw x lh part (nothing
+// beyond it is ever addressed: right indices are <= left indices in both axes).  A smaller one drops the window
+// terms whose right pixel does not exist (sad.go:225-227,231-233): generic kernel, see Job::rw.
+extern "C" int sadhip_disparity_lr_u8(sadhip_ctx* ctx,
+                                      const uint8_t* left, int lw, int lh, int lstride,
+                                      const uint8_t* right, int rw, int rh, int rstride,
+                                      int block, int maxdisp, unsigned flags,
+                                      int x0, int y0, int x1, int y1, uint8_t* out, int ostride)
+{
+  if (!ctx || !left || !right || !out) return fail(SADHIP_ERR_NULL, "ctx/left/right/out is NULL");
+  if (rw <= 0 || rh <= 0) return fail(SADHIP_ERR_DIMS, "right image %dx%d", rw, rh);
+  if (rstride < rw) return fail(SADHIP_ERR_STRIDE, "rstride=%d rw=%d", rstride, rw);
+  if (int st = check_params(lw, lh, lstride, lstride, block, maxdisp)) return st;
+  if (int st = check_flags(flags)) return st;
+  if (lw > ctx->max_w || lh > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", lw, lh, ctx->max_w, ctx->max_h);
+  if (x0 < 0 || y0 < 0 || x1 > lw || y1 > lh || x0 >= x1 || y0 >= y1)
+    return fail(SADHIP_ERR_REGION, "region (%d,%d)-(%d,%d) not inside %dx%d", x0, y0, x1, y1, lw, lh);
+  if (ostride < x1 - x0) return fail(SADHIP_ERR_STRIDE, "ostride=%d region width=%d", ostride, x1 - x0);
+  const bool smaller = rw < lw || rh < lh;
+  const unsigned mirrors = SADHIP_FLAG_MIRROR_SADC | SADHIP_FLAG_MIRROR_TESTPY | SADHIP_FLAG_MIRROR_VERILOG;
+  if (smaller && (flags & mirrors))
+    return fail(SADHIP_ERR_DIMS, "hardware-mirror modes need a right image of at least the left image's size (%dx%d < %dx%d)", rw, rh, lw, lh);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPTRY(hipSetDevice(ctx->device));
+  const auto t0 = clk::now();
+  const int hs = block / 2;
+  const int band0 = y0 - hs < 0 ? 0 : y0 - hs;
+  const int band1 = y1 + hs > lh ? lh : y1 + hs;
+  Slot& s = ctx->slot[0];
+  float kms = 0.f;
+  int st = enqueue_frame(ctx, s, left, right, lw, lh, lstride, rstride, block, maxdisp, flags, x0, y0, x1, y1, band0, band1, rw, rh);
+  if (st == SADHIP_OK) st = finish_frame(ctx, s, lw, x0, y0, x1, y1, out, ostride, &kms);
+  if (st != SADHIP_OK) { (void)hipStreamSynchronize(s.stream); return st; }
+  ctx->last_kernel_ms = kms;
+  ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+  return SADHIP_OK;
+}
+
 extern "C" int sadhip_disparity_u8(sadhip_ctx* ctx, const uint8_t* left, const uint8_t* right,
                                    int w, int h, int lstride, int rstride,
                                    int block, int maxdisp, unsigned flags, uint8_t* out, int ostride)
@@ -373,6 +580,81 @@ extern "C" int sadhip_disparity_u8(sadhip_ctx* ctx, const uint8_t* left, const u
   return SADHIP_OK;
 }
 
+// A batch whose frames all lie in page-locked memory: groups of kGroup frames, one kernel launch per group, linear
+// asynchronous copies (frames that follow each other in the caller's memory as one copy).  Three streams -- uploads,
+// kernels, downloads -- and per slot the events that chain them:
+//   upload g    waits for kernel g-S (it read the slot's input planes)          -> records up
+//   kernel g    waits for up, and for download g-S (it read the slot's output)  -> records k0 .. k1
+//   download g  waits for k1                                                    -> records down
+// The host runs at most S groups ahead (it waits for download g-S before it reuses a slot) and drains all three
+// streams before it returns -- on errors too.  The caller holds ctx->mu and has validated everything.
+static int batch_pinned(sadhip_ctx* c, int n, const uint8_t* const* lefts, const uint8_t* const* rights,
+                        int w, int h, int lstride, int rstride, int block, int maxdisp, unsigned flags,
+                        uint8_t* const* outs, int ostride, float* kms)
+{
+  if (int st = ensure_groups(c)) return st;
+  constexpr int G = sadhip_ctx::kGroup, S = sadhip_ctx::kGroupSlots;
+  const size_t fl = (size_t)lstride * h, fr = (size_t)rstride * h, fo = (size_t)ostride * h;      // frame to frame
+  const size_t cl = fl - lstride + w, cr = fr - rstride + w, co = fo - ostride + w;               // bytes of one frame
+  const int ng = (n + G - 1) / G;
+  // copies of frames [i0, i0 + cnt): a run of frames that follow each other at exactly `step` bytes inside ONE
+  // page-locked range travels as one copy
+  auto copy_runs = [&](hipStream_t st, uint8_t* dev, const uint8_t* const* host, int i0, int cnt, size_t step, size_t one, bool to_dev) -> int {
+    for (int i = 0; i < cnt;) {
+      int k = i + 1;
+      while (k < cnt && host[i0 + k] == host[i0 + k - 1] + step) ++k;
+      if (k - i > 1 && !is_pinned(host[i0 + i], (size_t)(k - i - 1) * step + one)) k = i + 1;
+      const size_t bytes = (size_t)(k - i - 1) * step + one;
+      if (to_dev) HIPTRY(hipMemcpyAsync(dev + (size_t)i * step, host[i0 + i], bytes, hipMemcpyHostToDevice, st));
+      else HIPTRY(hipMemcpyAsync(const_cast<uint8_t*>(host[i0 + i]), dev + (size_t)i * step, bytes, hipMemcpyDeviceToHost, st));
+      i = k;
+    }
+    return SADHIP_OK;
+  };
+  auto body = [&]() -> int {
+    for (int g = 0; g < ng; ++g) {
+      sadhip_ctx::GroupSlot& s = c->grp[g % S];
+      const int i0 = g * G, cnt = n - i0 < G ? n - i0 : G;
+      if (g >= S) {                                             // the slot's previous group: results home, kernel time read
+        HIPTRY(hipEventSynchronize(s.down));
+        float ms = 0.f;
+        HIPTRY(hipEventElapsedTime(&ms, s.k0, s.k1));
+        *kms += ms;
+        HIPTRY(hipStreamWaitEvent(c->s_up, s.k1, 0));          // (complete already: the download waited for it)
+      }
+      if (int st = copy_runs(c->s_up, s.dL, lefts, i0, cnt, fl, cl, true)) return st;
+      if (int st = copy_runs(c->s_up, s.dR, rights, i0, cnt, fr, cr, true)) return st;
+      HIPTRY(hipEventRecord(s.up, c->s_up));
+      Job j{};
+      j.left = s.dL; j.right = s.dR; j.out = s.dO;
+      j.left_frame_stride = fl; j.right_frame_stride = fr; j.out_frame_stride = fo;
+      j.lstride = lstride; j.rstride = rstride; j.ostride = ostride;
+      j.n = cnt; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
+      j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.ox = 0; j.oy = 0;
+      j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
+      HIPTRY(hipStreamWaitEvent(c->s_kern, s.up, 0));
+      HIPTRY(hipEventRecord(s.k0, c->s_kern));
+      HIPTRY(dispatch(j, flags, c->s_kern));
+      HIPTRY(hipEventRecord(s.k1, c->s_kern));
+      HIPTRY(hipStreamWaitEvent(c->s_down, s.k1, 0));
+      if (int st = copy_runs(c->s_down, s.dO, outs, i0, cnt, fo, co, false)) return st;
+      HIPTRY(hipEventRecord(s.down, c->s_down));
+    }
+    for (int g = ng > S ? ng - S : 0; g < ng; ++g) {            // the groups still in flight
+      sadhip_ctx::GroupSlot& s = c->grp[g % S];
+      HIPTRY(hipEventSynchronize(s.down));
+      float ms = 0.f;
+      HIPTRY(hipEventElapsedTime(&ms, s.k0, s.k1));
+      *kms += ms;
+    }
+    return SADHIP_OK;
+  };
+  const int st = body();
+  // nothing from / to the caller's memory stays in flight, whatever happened
+  for (hipStream_t q : {c->s_up, c->s_kern, c->s_down}) (void)hipStreamSynchronize(q);
+  return st;
+}
+
 extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
                                          const uint8_t* const* lefts, const uint8_t* const* rights,
                                          int w, int h, int lstride, int rstride,
@@ -393,6 +675,20 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
   HIPTRY(hipSetDevice(ctx->device));
   const auto t0 = clk::now();
   float kms = 0.f;
+  {
+    // every frame in page-locked memory this library knows, frames fit the device planes at the caller's strides
+    bool pinned = !ctx->pinned_staging && (size_t)lstride * h <= ctx->plane && (size_t)rstride * h <= ctx->plane &&
+                  (size_t)ostride * h <= ctx->plane;
+    const size_t cl = (size_t)lstride * (h - 1) + w, cr = (size_t)rstride * (h - 1) + w, co = (size_t)ostride * (h - 1) + w;
+    for (int i = 0; i < n && pinned; ++i)
+      pinned = is_pinned(lefts[i], cl) && is_pinned(rights[i], cr) && is_pinned(outs[i], co);
+    if (pinned) {
+      if (int st = batch_pinned(ctx, n, lefts, rights, w, h, lstride, rstride, block, maxdisp, flags, outs, ostride, &kms)) return st;
+      ctx->last_kernel_ms = kms;
+      ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+      return SADHIP_OK;
+    }
+  }
   // two-slot software pipeline: while slot A's frame is on the GPU, the host stages and
   // enqueues the next frame on slot B, then drains A.
 #ifdef SADHIP_TUNING

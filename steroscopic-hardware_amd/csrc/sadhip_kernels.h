@@ -17,7 +17,13 @@ struct Job {
   const uint8_t* right; size_t right_frame_stride; int rstride;
   uint8_t* out;         size_t out_frame_stride;   int ostride;
   int n;                 // frames
-  int w, h;              // image size
+  int w, h;              // image size (the LEFT image's: windows clamp to it, sad.go:212-215)
+  // Size of the right image when it is SMALLER than the left one in a dimension (0 = at least w / h).  The
+  // reference walks the right window with the left window's extent and breaks where it leaves right.Rect.Max
+  // (sad.go:225-227,231-233): terms whose right pixel lies outside the right image are dropped.  Only the generic
+  // kernel implements that; fast_supported() is false for such a job.  A larger right image needs nothing: no
+  // right pixel beyond (w, h) is ever addressed.
+  int rw, rh;
   int block, maxdisp;    // BlockSize, MaxDisparity (pkg/despair/params.go:32-37)
   int x0, y0, x1, y1;    // output rectangle (image coordinates)
   int ox, oy;            // output buffer origin (image coordinates)
@@ -44,8 +50,9 @@ hipError_t launch_mirror(const Job& j, int mode, hipStream_t s);
 // Fast kernel (kernels_fast.hip): returns true if it supports the job's parameters.
 bool fast_supported(const Job& j);
 hipError_t launch_fast(const Job& j, hipStream_t s);
-// Text description of the passes launch_fast would run (empty when it would not): see sadhip_plan_describe.
-int describe_fast(const Job& j, char* buf, int cap);
+// Text description of the passes launch_fast would run (empty when it would not): see sadhip_plan_describe;
+// geometry: append tiles / strips / rows per strip / workgroups per CU of a launch of j.n frames on the current device.
+int describe_fast(const Job& j, char* buf, int cap, bool geometry);
 
 // Single-window SADs, literal clamps of sad.go:205-244.
 hipError_t launch_sad_windows(const uint8_t* left, int lw, int lh, int lstride,

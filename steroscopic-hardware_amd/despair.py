@@ -138,7 +138,10 @@ def SetupConcurrentSAD(numWorkers):
                 h, w = chunk.Left.shape
                 try:
                     with _context(w, h) as c:
-                        data = c.disparity_region(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity, chunk.Region)
+                        if chunk.Right.shape == chunk.Left.shape:
+                            data = c.disparity_region(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity, chunk.Region)
+                        else:       # independently decoded pictures (output.go:134-162): the reference's clamps, sad.go:212-233
+                            data = c.disparity_lr(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity, chunk.Region)
                 except Exception as e:                          # noqa: BLE001 -- carried to the consumer
                     outp.error = e
                     failed = True
@@ -173,10 +176,14 @@ def AssembleDisparityMap(outputChan, dimensions, chunks):
 def RunSad(left, right, blockSize, maxDisparity):
     """sad.go:119-169: sets the global parameters (:123-126) and returns the full map.
     One frame-level device call replaces tiling + channel assembly (values do not depend on
-    the tiling: every worker reads the full shared images, sad.go:69-77)."""
+    the tiling: every worker reads the full shared images, sad.go:69-77).  The map has the LEFT image's
+    size (sad.go:131,168); a right image of another size is handled as the reference's loops do
+    (sadhip_disparity_lr_u8: sad.go:212-218,225-227,231-233), never read past its end."""
     SetDefaultParams(Parameters(BlockSize=blockSize, MaxDisparity=maxDisparity))
     h, w = left.shape
     with _context(w, h) as c:
+        if right.shape != left.shape:
+            return c.disparity_lr(left, right, blockSize, maxDisparity)
         return c.disparity(left, right, blockSize, maxDisparity)
 
 

@@ -101,10 +101,12 @@ Pipeline SetupConcurrentSAD(int numWorkers, int device)
         o.DisparityData.assign((size_t)c.Region.Dx() * c.Region.Dy(), 0);              // sad.go:48-50
         const Gray& L = *c.Left; const Gray& R = *c.Right;
         Lease ctx(device, L.Rect.Dx(), L.Rect.Dy());
-        check(sadhip_disparity_region_u8(ctx.get(), L.Pix.data(), R.Pix.data(),
-                                         L.Rect.Dx(), L.Rect.Dy(), L.Stride, R.Stride, prm.BlockSize, prm.MaxDisparity, 0,
-                                         c.Region.x0, c.Region.y0, c.Region.x1, c.Region.y1, o.DisparityData.data()),
-              "sadhip_disparity_region_u8");
+        // each image with its OWN size: the two pictures are decoded independently (pkg/camera/output.go:134-162) and
+        // the reference clamps / breaks per image (sad.go:212-218,225-227,231-233) -- never w x h of a smaller R
+        check(sadhip_disparity_lr_u8(ctx.get(), L.Pix.data(), L.Rect.Dx(), L.Rect.Dy(), L.Stride,
+                                     R.Pix.data(), R.Rect.Dx(), R.Rect.Dy(), R.Stride, prm.BlockSize, prm.MaxDisparity, 0,
+                                     c.Region.x0, c.Region.y0, c.Region.x1, c.Region.y1, o.DisparityData.data(), c.Region.Dx()),
+              "sadhip_disparity_lr_u8");
       } catch (...) {
         out->fail(std::current_exception());                                           // the consumer gets the error, not a short stream
         failed = true;
@@ -142,12 +144,18 @@ Gray AssembleDisparityMap(Chan<OutputChunk>& out, Rectangle dimensions, int chun
 Gray RunSad(const Gray& left, const Gray& right, int blockSize, int maxDisparity, int device)
 {
   SetDefaultParams(Parameters{blockSize, maxDisparity});                                // sad.go:123-126
-  Gray out(left.Rect);
+  Gray out(left.Rect);                                                                  // sad.go:135,168: the LEFT image's rectangle
   Lease ctx(dev_or_default(device), left.Rect.Dx(), left.Rect.Dy());
-  check(sadhip_disparity_u8(ctx.get(), left.Pix.data(), right.Pix.data(),
-                            left.Rect.Dx(), left.Rect.Dy(), left.Stride, right.Stride, blockSize, maxDisparity, 0,
-                            out.Pix.data(), out.Stride),
-        "sadhip_disparity_u8");
+  if (right.Rect.Dx() == left.Rect.Dx() && right.Rect.Dy() == left.Rect.Dy())
+    check(sadhip_disparity_u8(ctx.get(), left.Pix.data(), right.Pix.data(),
+                              left.Rect.Dx(), left.Rect.Dy(), left.Stride, right.Stride, blockSize, maxDisparity, 0,
+                              out.Pix.data(), out.Stride),
+          "sadhip_disparity_u8");
+  else                                                                                  // sizes differ: the reference's clamps (sad.go:212-233)
+    check(sadhip_disparity_lr_u8(ctx.get(), left.Pix.data(), left.Rect.Dx(), left.Rect.Dy(), left.Stride,
+                                 right.Pix.data(), right.Rect.Dx(), right.Rect.Dy(), right.Stride, blockSize, maxDisparity, 0,
+                                 0, 0, left.Rect.Dx(), left.Rect.Dy(), out.Pix.data(), out.Stride),
+          "sadhip_disparity_lr_u8");
   note_timing(ctx.get());
   return out;
 }
@@ -219,9 +227,8 @@ Gray LoadPNG(const std::string& filename, LoadPNGOptions opt) { return ToGray(Lo
 
 Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDisparity, int device, int* uploads_out)
 {
-  if (left.w != right.w || left.h != right.h)
-    throw Error(SADHIP_ERR_DIMS, "RunSad: left and right pictures differ in size");
-  if (left.device_gray_ok() && right.device_gray_ok() && left.channels == right.channels) {
+  // pictures of different sizes (left.png / right.png are uploaded independently): gray planes + the lr entry below
+  if (left.w == right.w && left.h == right.h && left.device_gray_ok() && right.device_gray_ok() && left.channels == right.channels) {
     SetDefaultParams(Parameters{blockSize, maxDisparity});                              // sad.go:123-126
     Gray out(left.w, left.h);
     Lease ctx(dev_or_default(device), left.w, left.h);
@@ -247,6 +254,16 @@ void SavePNG(const std::string& filename, const Gray& img)
   if (!write_png_gray8(filename, img.Pix.data(), img.Rect.Dx(), img.Rect.Dy(), img.Stride, &err))
     throw Error(SADHIP_ERR_ARG, "SavePNG " + filename + ": " + err);
 }
+
+// ---- page-locked frames --------------------------------------------------------------------------
+HostFrames::HostFrames(int n, int w, int h) : n_(n), w_(w), h_(h)
+{
+  if (n < 1 || w < 1 || h < 1) throw Error(SADHIP_ERR_DIMS, "HostFrames: n, w, h must be positive");
+  void* p = nullptr;
+  check(sadhip_host_alloc((size_t)n * w * h, &p), "sadhip_host_alloc");
+  base_ = static_cast<uint8_t*>(p);
+}
+HostFrames::~HostFrames() { if (base_) sadhip_host_free(base_); }
 
 // ---- several devices -----------------------------------------------------------------------------
 DevicePool::DevicePool(const std::vector<int>& devices, int max_w, int max_h)
@@ -279,6 +296,18 @@ std::vector<Gray> DevicePool::RunSadBatch(const std::vector<std::shared_ptr<cons
   check(sadhip_pool_batch_u8(p_, (int)lefts.size(), pl.data(), pr.data(), r.Dx(), r.Dy(), ls, rs, blockSize, maxDisparity, 0,
                              po.data(), r.Dx()), "sadhip_pool_batch_u8");
   return outs;
+}
+
+void DevicePool::RunSadBatch(const HostFrames& lefts, const HostFrames& rights, HostFrames& outs, int blockSize, int maxDisparity)
+{
+  const int n = lefts.size(), w = lefts.width(), h = lefts.height();
+  if (rights.size() != n || outs.size() != n || rights.width() != w || outs.width() != w || rights.height() != h || outs.height() != h)
+    throw Error(SADHIP_ERR_DIMS, "RunSadBatch: lefts / rights / outs must share length and frame size");
+  SetDefaultParams(Parameters{blockSize, maxDisparity});
+  std::vector<const uint8_t*> pl((size_t)n), pr((size_t)n);
+  std::vector<uint8_t*> po((size_t)n);
+  for (int i = 0; i < n; ++i) { pl[(size_t)i] = lefts.frame(i); pr[(size_t)i] = rights.frame(i); po[(size_t)i] = outs.frame(i); }
+  check(sadhip_pool_batch_u8(p_, n, pl.data(), pr.data(), w, h, w, w, blockSize, maxDisparity, 0, po.data(), w), "sadhip_pool_batch_u8");
 }
 
 }  // namespace despair

@@ -139,6 +139,24 @@ Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDis
 // device / wall time of the last RunSad of the calling thread ("elapsed" of output.go:200-204)
 void LastTiming(float* kernel_ms, float* total_ms);
 
+// ---- page-locked frames (sadhip_host_alloc): n frames of w x h u8, one contiguous block ------------
+// What a capture pipeline fills instead of pageable Gray.Pix when it streams frames to the device: the
+// host-buffer entry points recognise the memory and copy asynchronously at bus speed (include/sadhip.h).
+class HostFrames {
+ public:
+  HostFrames(int n, int w, int h);
+  ~HostFrames();
+  HostFrames(const HostFrames&) = delete;
+  HostFrames& operator=(const HostFrames&) = delete;
+  int size() const { return n_; }
+  int width() const { return w_; }
+  int height() const { return h_; }
+  uint8_t* frame(int i) { return base_ + (size_t)i * w_ * h_; }
+  const uint8_t* frame(int i) const { return base_ + (size_t)i * w_ * h_; }
+ private:
+  uint8_t* base_ = nullptr; int n_ = 0, w_ = 0, h_ = 0;
+};
+
 // ---- several devices: frame i of a batch runs on devices[i mod G] --------------------
 class DevicePool {
  public:
@@ -150,6 +168,8 @@ class DevicePool {
   // one map per pair; the global parameters are set like RunSad does (sad.go:123-126)
   std::vector<Gray> RunSadBatch(const std::vector<std::shared_ptr<const Gray>>& lefts,
                                 const std::vector<std::shared_ptr<const Gray>>& rights, int blockSize, int maxDisparity);
+  // the same on page-locked frames, results into page-locked frames (all three of one size and length)
+  void RunSadBatch(const HostFrames& lefts, const HostFrames& rights, HostFrames& outs, int blockSize, int maxDisparity);
  private:
   sadhip_pool* p_ = nullptr;
 };

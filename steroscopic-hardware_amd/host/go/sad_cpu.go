@@ -22,6 +22,12 @@ func RunSad(left, right *image.Gray, blockSize, maxDisparity int) *image.Gray {
 	return runSadGo(left, right, blockSize, maxDisparity)
 }
 
+// RunSadFrame exists so that pkg/camera compiles in both builds (patch 0002); with FrameLevel == false it is
+// never called.  In the hip build it is RunSad without the write to the process-wide parameters.
+func RunSadFrame(left, right *image.Gray, p Parameters) *image.Gray {
+	return runSadGo(left, right, p.BlockSize, p.MaxDisparity)
+}
+
 // AssembleDisparityMap assembles the disparity map from output chunks (sad.go:172-202).
 func AssembleDisparityMap(outputChan <-chan OutputChunk, dimensions image.Rectangle, chunks int) *image.Gray {
 	return assembleDisparityMapGo(outputChan, dimensions, chunks)

@@ -111,17 +111,24 @@ func regionHIP(left, right *image.Gray, p Parameters, r image.Rectangle) ([]uint
 	if len(data) == 0 {
 		return data, nil
 	}
+	if len(left.Pix) == 0 || len(right.Pix) == 0 {
+		return nil, fmt.Errorf("empty image") // the Go path handles it (it yields zeros)
+	}
+	// Each image travels with its OWN size: left.png and right.png are decoded independently
+	// (pkg/camera/output.go:134-162) and the reference clamps per image (sad.go:212-218) and breaks where
+	// the right window leaves right.Rect.Max (sad.go:225-227,231-233).  Passing the left image's
+	// dimensions for both would read past the end of a smaller right.Pix.
 	err := ctx.with(left.Rect.Dx(), left.Rect.Dy(), func(h *C.sadhip_ctx) error {
-		st := C.sadhip_disparity_region_u8(h,
-			(*C.uint8_t)(unsafe.Pointer(&left.Pix[0])), (*C.uint8_t)(unsafe.Pointer(&right.Pix[0])),
-			C.int(left.Rect.Dx()), C.int(left.Rect.Dy()), C.int(left.Stride), C.int(right.Stride),
+		st := C.sadhip_disparity_lr_u8(h,
+			(*C.uint8_t)(unsafe.Pointer(&left.Pix[0])), C.int(left.Rect.Dx()), C.int(left.Rect.Dy()), C.int(left.Stride),
+			(*C.uint8_t)(unsafe.Pointer(&right.Pix[0])), C.int(right.Rect.Dx()), C.int(right.Rect.Dy()), C.int(right.Stride),
 			C.int(p.BlockSize), C.int(p.MaxDisparity), 0,
 			C.int(r.Min.X), C.int(r.Min.Y), C.int(r.Max.X), C.int(r.Max.Y),
-			(*C.uint8_t)(unsafe.Pointer(&data[0])))
+			(*C.uint8_t)(unsafe.Pointer(&data[0])), C.int(r.Dx()))
 		runtime.KeepAlive(left)
 		runtime.KeepAlive(right)
 		if st != C.SADHIP_OK {
-			return statusErr("sadhip_disparity_region_u8", st)
+			return statusErr("sadhip_disparity_lr_u8", st)
 		}
 		return nil
 	})
@@ -169,31 +176,37 @@ func SetupConcurrentSAD(numWorkers int) (chan<- InputChunk, <-chan OutputChunk) 
 	return inputChan, outputChan
 }
 
-// RunSad computes the full disparity map with one device call (sad.go:119-169).
+// RunSad computes the full disparity map with one device call (sad.go:119-169) and, like the
+// reference, records the parameters as the process defaults (sad.go:123-126).
 func RunSad(left, right *image.Gray, blockSize, maxDisparity int) *image.Gray {
 	SetDefaultParams(Parameters{BlockSize: blockSize, MaxDisparity: maxDisparity})
-	out := image.NewGray(left.Rect)
+	return RunSadFrame(left, right, Parameters{BlockSize: blockSize, MaxDisparity: maxDisparity})
+}
+
+// RunSadFrame is RunSad WITHOUT the write to the process-wide parameters: what a frame loop calls that
+// only READS them (pkg/camera/output.go:169 -- patches/0002).  Calling RunSad there would write the
+// values read at the start of the frame back over an update the UI handler made meanwhile
+// (cmd/handlers/params.go:56-59) and lose it.
+func RunSadFrame(left, right *image.Gray, p Parameters) *image.Gray {
+	out := image.NewGray(left.Rect) // sad.go:135,168: the LEFT image's rectangle
 	if len(out.Pix) == 0 {
 		return out
 	}
-	err := ctx.with(left.Rect.Dx(), left.Rect.Dy(), func(h *C.sadhip_ctx) error {
-		st := C.sadhip_disparity_u8(h,
-			(*C.uint8_t)(unsafe.Pointer(&left.Pix[0])), (*C.uint8_t)(unsafe.Pointer(&right.Pix[0])),
-			C.int(left.Rect.Dx()), C.int(left.Rect.Dy()), C.int(left.Stride), C.int(right.Stride),
-			C.int(blockSize), C.int(maxDisparity), 0,
-			(*C.uint8_t)(unsafe.Pointer(&out.Pix[0])), C.int(out.Stride))
-		runtime.KeepAlive(left)
-		runtime.KeepAlive(right)
-		if st != C.SADHIP_OK {
-			return statusErr("sadhip_disparity_u8", st)
-		}
-		return nil
-	})
+	data, err := regionHIP(left, right, p, left.Rect) // one call; left and right with their own sizes
 	if err == nil {
+		for y := 0; y < left.Rect.Dy(); y++ {
+			copy(out.Pix[y*out.Stride:y*out.Stride+left.Rect.Dx()], data[y*left.Rect.Dx():(y+1)*left.Rect.Dx()])
+		}
 		return out
 	}
 	slog.Warn("HIP disparity failed, using the Go path", "err", err)
-	return runSadGo(left, right, blockSize, maxDisparity)
+	// the reference's worker on the whole frame as one chunk; it snapshots the process-wide parameters per
+	// chunk itself (sad.go:51-53) and writes nothing back
+	chunk := regionGo(InputChunk{Left: left, Right: right, Region: left.Rect})
+	for y := 0; y < left.Rect.Dy(); y++ {
+		copy(out.Pix[y*out.Stride:y*out.Stride+left.Rect.Dx()], chunk.DisparityData[y*left.Rect.Dx():(y+1)*left.Rect.Dx()])
+	}
+	return out
 }
 
 // AssembleDisparityMap assembles the disparity map from output chunks (sad.go:172-202).

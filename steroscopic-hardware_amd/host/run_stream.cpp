@@ -73,6 +73,18 @@ int main(int argc, char** argv)
       for (const Gray& m : maps)
         if (m.Pix != once.Pix) { fprintf(stderr, "device pool and RunSad disagree\n"); return 1; }
       printf("Pool of %d contexts: %d frames in %.3f ms\n", pool.size(), frames, ms);
+      // the same batch from page-locked frames (sadhip_host_alloc): asynchronous copies at bus speed
+      HostFrames hl(frames, w, h), hr(frames, w, h), ho(frames, w, h);
+      for (int i = 0; i < frames; ++i) {
+        memcpy(hl.frame(i), L->Pix.data(), L->Pix.size()); memcpy(hr.frame(i), R->Pix.data(), R->Pix.size());
+        memset(ho.frame(i), 0xEE, (size_t)w * h);
+      }
+      const auto t1 = std::chrono::steady_clock::now();
+      pool.RunSadBatch(hl, hr, ho, block, maxdisp);
+      const double ms1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+      for (int i = 0; i < frames; ++i)
+        if (memcmp(ho.frame(i), once.Pix.data(), once.Pix.size()) != 0) { fprintf(stderr, "device pool (page-locked frames) and RunSad disagree\n"); return 1; }
+      printf("Pool of %d contexts, page-locked frames: %d frames in %.3f ms\n", pool.size(), frames, ms1);
     }
     std::ofstream(pos[7], std::ios::binary).write(reinterpret_cast<const char*>(got.Pix.data()), (std::streamsize)got.Pix.size());
     printf("SAD(100,50 vs 95,50) = %d\n", w > 110 && h > 60 ? SumAbsoluteDifferences(*L, *R, 100, 50, 95, 50, block) : -1);

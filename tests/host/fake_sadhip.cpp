@@ -84,6 +84,22 @@ int sadhip_disparity_region_u8(sadhip_ctx* c, const uint8_t* L, const uint8_t* R
     for (int x = x0; x < x1; ++x) out[(size_t)(y - y0) * (x1 - x0) + (x - x0)] = (uint8_t)((L[(size_t)y * ls + x] ^ R[(size_t)y * rs + x]) + block);
   return SADHIP_OK;
 }
+// Left and right with their own sizes: reads R ONLY inside rw x rh (a binding that passed the wrong size or a too
+// small buffer is caught by AddressSanitizer in the asan build); a missing right pixel counts as 0.
+int sadhip_disparity_lr_u8(sadhip_ctx* c, const uint8_t* L, int lw, int lh, int ls, const uint8_t* R, int rw, int rh, int rs,
+                           int block, int maxdisp, unsigned, int x0, int y0, int x1, int y1, uint8_t* out, int os)
+{
+  InCall g(c);
+  if (lw > c->w || lh > c->h) { g_violations.fetch_add(1); return SADHIP_ERR_DIMS; }
+  if (rw <= 0 || rh <= 0) return SADHIP_ERR_DIMS;
+  if (int st = inject(maxdisp)) return st;
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      const uint8_t r = (x < rw && y < rh) ? R[(size_t)y * rs + x] : 0;
+      out[(size_t)(y - y0) * os + (x - x0)] = (uint8_t)((L[(size_t)y * ls + x] ^ r) + block);
+    }
+  return SADHIP_OK;
+}
 int sadhip_disparity_u8(sadhip_ctx* c, const uint8_t* L, const uint8_t* R, int w, int h, int ls, int rs,
                         int block, int maxdisp, unsigned, uint8_t* out, int os)
 {
@@ -117,6 +133,9 @@ int sadhip_gray_u8(sadhip_ctx* c, const uint8_t* pix, int ch, int w, int h, int 
   return SADHIP_OK;
 }
 int sadhip_last_timing(sadhip_ctx*, float* k, float* t) { if (k) *k = 0.1f; if (t) *t = 0.2f; return SADHIP_OK; }
+
+int sadhip_host_alloc(size_t bytes, void** out) { *out = ::operator new(bytes); return SADHIP_OK; }
+int sadhip_host_free(void* p) { ::operator delete(p); return SADHIP_OK; }
 
 int sadhip_pool_create(const int* devices, int n, int w, int h, sadhip_pool** out)
 {

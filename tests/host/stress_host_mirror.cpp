@@ -6,7 +6,10 @@
 //   2. pipelines on two devices at once keep their own contexts;
 //   3. a device error inside the pipeline worker reaches AssembleDisparityMap as a despair::Error and
 //      the feeder thread is released (no hang, no silently short map);
-//   4. the device pool wrapper returns every frame.
+//   4. the device pool wrapper returns every frame;
+//   5. left and right images of different sizes (the WebUI uploads them independently, pkg/camera/output.go:134-162):
+//      RunSad and the pipeline worker hand each image over with its own size -- the right image is allocated at
+//      exactly rw x rh bytes, so the asan build (make asan-host) turns any read past it into a failure.
 #include "../../steroscopic-hardware_amd/host/despair.hpp"
 #include "../../include/sadhip.h"
 
@@ -30,14 +33,18 @@ static std::shared_ptr<Gray> image(int w, int h, int seed)
 
 static bool check_map(const Gray& got, const Gray& L, const Gray& R, int block)
 {
-  for (size_t i = 0; i < got.Pix.size(); ++i)
-    if (got.Pix[i] != (uint8_t)((L.Pix[i] ^ R.Pix[i]) + block)) return false;
+  if (got.Rect.Dx() != L.Rect.Dx() || got.Rect.Dy() != L.Rect.Dy()) return false;      // the map has the LEFT image's size (sad.go:135,168)
+  for (int y = 0; y < L.Rect.Dy(); ++y)
+    for (int x = 0; x < L.Rect.Dx(); ++x) {
+      const uint8_t r = (x < R.Rect.Dx() && y < R.Rect.Dy()) ? R.Pix[(size_t)y * R.Stride + x] : 0;
+      if (got.Pix[(size_t)y * got.Stride + x] != (uint8_t)((L.Pix[(size_t)y * L.Stride + x] ^ r) + block)) return false;
+    }
   return true;
 }
 
-static bool run_pipeline(int device, int w, int h, int block, int chunk_rows)
+static bool run_pipeline(int device, int w, int h, int block, int chunk_rows, int rw = 0, int rh = 0)
 {
-  auto L = image(w, h, 1), R = image(w, h, 2);
+  auto L = image(w, h, 1), R = image(rw > 0 ? rw : w, rh > 0 ? rh : h, 2);
   Pipeline p = SetupConcurrentSAD(2, device);                    // capacity 4: the feeder really blocks
   const int chunks = (h + chunk_rows - 1) / chunk_rows;
   std::thread feeder([&] { for (int y = 0; y < h; y += chunk_rows) p.in->send(InputChunk{L, R, Rectangle{0, y, w, std::min(y + chunk_rows, h)}}); });
@@ -106,6 +113,21 @@ int main()
     const std::vector<Gray> maps = pool.RunSadBatch(ls, rs, block, 64);
     if (maps.size() != 7 || pool.size() != 3) { fprintf(stderr, "FAIL: pool size\n"); return 1; }
     for (int i = 0; i < 7; ++i) if (!check_map(maps[i], *ls[i], *rs[i], block)) { fprintf(stderr, "FAIL: pool frame %d\n", i); return 1; }
+    HostFrames hl(7, 200, 100), hr(7, 200, 100), ho(7, 200, 100);                  // the page-locked overload
+    for (int i = 0; i < 7; ++i) { std::copy(ls[i]->Pix.begin(), ls[i]->Pix.end(), hl.frame(i)); std::copy(rs[i]->Pix.begin(), rs[i]->Pix.end(), hr.frame(i)); }
+    pool.RunSadBatch(hl, hr, ho, block, 64);
+    for (int i = 0; i < 7; ++i)
+      if (!std::equal(maps[i].Pix.begin(), maps[i].Pix.end(), ho.frame(i))) { fprintf(stderr, "FAIL: pool page-locked frame %d\n", i); return 1; }
+  }
+  // ---- 5: left / right of different sizes ---------------------------------------------------------
+  {
+    const int sizes[][4] = {{320, 200, 300, 180}, {320, 200, 320, 150}, {320, 200, 17, 200}, {320, 200, 400, 260}, {64, 48, 1, 1}, {320, 200, 330, 190}};
+    for (const auto& z : sizes) {
+      auto L = image(z[0], z[1], 3), R = image(z[2], z[3], 4);
+      const Gray got = RunSad(*L, *R, block, 64);
+      if (!check_map(got, *L, *R, block)) { fprintf(stderr, "FAIL: RunSad %dx%d vs %dx%d\n", z[0], z[1], z[2], z[3]); return 1; }
+      if (!run_pipeline(0, z[0], z[1], block, 13, z[2], z[3])) { fprintf(stderr, "FAIL: pipeline %dx%d vs %dx%d\n", z[0], z[1], z[2], z[3]); return 1; }
+    }
   }
   if (fake_violations()) { fprintf(stderr, "FAIL: %d context lifetime violations\n", fake_violations()); return 1; }
   printf("OK contexts=%d calls=%d violations=%d\n", fake_created(), fake_calls(), fake_violations());

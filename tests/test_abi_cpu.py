@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     l = C.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(l, name), f"{name} not exported"
-    assert capi.lib().sadhip_abi_version() == capi.ABI_VERSION == 2
+    assert capi.lib().sadhip_abi_version() == capi.ABI_VERSION == 3
 
 
 def test_status_strings():

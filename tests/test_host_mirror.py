@@ -36,11 +36,12 @@ def test_go_shim_and_patches_are_reviewable():
     hip = open(os.path.join(GO, "sad_hip.go")).read()
     cpu = open(os.path.join(GO, "sad_cpu.go")).read()
     assert hip.startswith("//go:build cgo && hip") and cpu.startswith("//go:build !(cgo && hip)")
-    for name in ("func SetupConcurrentSAD(", "func RunSad(", "func AssembleDisparityMap(", "FrameLevel"):
+    for name in ("func SetupConcurrentSAD(", "func RunSad(", "func RunSadFrame(", "func AssembleDisparityMap(", "FrameLevel"):
         assert name in hip and name in cpu, name
     assert "cpuRegion" not in hip and "SumAbsoluteDifferences(" not in hip        # no restated reference loop
     for ref in ("setupConcurrentSADGo(", "runSadGo("):
-        assert ref in hip and ref in cpu
+        assert ref in cpu
+    assert "setupConcurrentSADGo(" in hip                                         # every fallback is the reference's own worker
     assert "assembleDisparityMapGo(" in cpu
     assert "sync.RWMutex" in hip and "runtime.LockOSThread()" in hip and 'os.Getenv("SADHIP_DEVICE")' in hip
     assert not os.path.exists(os.path.join(GO, "output_fastpath.go.txt"))
@@ -49,7 +50,10 @@ def test_go_shim_and_patches_are_reviewable():
     p1 = open(os.path.join(GO, "patches", patches[0])).read()
     p2 = open(os.path.join(GO, "patches", patches[1])).read()
     assert p1.startswith("--- a/pkg/despair/sad.go") and "+func setupConcurrentSADGo(" in p1 and "+func runSadGo(" in p1
-    assert p2.startswith("--- a/pkg/camera/output.go") and "despair.RunSad(leftImg, rightImg, params.BlockSize, params.MaxDisparity)" in p2
+    # the frame loop only READS the parameters: it calls RunSadFrame, which writes nothing back
+    assert p2.startswith("--- a/pkg/camera/output.go") and "despair.RunSadFrame(leftImg, rightImg, *params)" in p2 and "despair.RunSad(" not in p2
+    # each image travels with its OWN size (the reference tolerates a smaller right image, sad.go:225-233)
+    assert "sadhip_disparity_lr_u8" in hip and "right.Rect.Dx()" in hip and "sadhip_disparity_region_u8" not in hip and "C.sadhip_disparity_u8" not in hip
     ref = "/root/reference"
     if os.path.isdir(os.path.join(ref, "pkg", "despair")):
         for pf in patches:
@@ -67,6 +71,18 @@ def test_host_logic_under_thread_sanitizer():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert re.search(r"OK contexts=\d+ calls=\d+ violations=0", r.stdout), r.stdout
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_host_logic_under_address_sanitizer_with_mismatched_picture_sizes():
+    """The same program under AddressSanitizer + UBSan.  Its phase 5 runs RunSad and the pipeline worker on
+    left / right images of different sizes with the right image allocated at exactly its own size: a binding
+    that passed the left image's dimensions for both (round 2's did) reads past it and fails here."""
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host"), "asan-host"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(LIB, "host_stress_asan")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0 halt_on_error=1 exitcode=67"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert re.search(r"OK contexts=\d+ calls=\d+ violations=0", r.stdout), r.stdout
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
 
 
 @pytest.mark.gpu
@@ -91,7 +107,7 @@ def test_run_stream_device_pool_and_failure_exit(tmp_path):
     args = [EXE, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), "400", "150", "16", "64", str(tmp_path / "o.raw"), "5"]
     out = subprocess.run(args + ["--devices", "0,0"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr + out.stdout
-    assert "Pool of 2 contexts: 5 frames" in out.stdout
+    assert "Pool of 2 contexts: 5 frames" in out.stdout and "Pool of 2 contexts, page-locked frames: 5 frames" in out.stdout
     assert np.array_equal(np.fromfile(tmp_path / "o.raw", np.uint8).reshape(150, 400), oracle.disparity_closed(L, R, 16, 64))
     bad = subprocess.run(args[:6] + ["0", str(tmp_path / "o2.raw"), "2"], capture_output=True, text=True, timeout=60)   # MaxDisparity 0
     assert bad.returncode == 3 and "despair error" in bad.stderr

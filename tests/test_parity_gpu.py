@@ -396,6 +396,71 @@ def test_regions_like_the_callers(ctx, flags):
         assert np.array_equal(ctx.disparity_region(L, R, 9, 64, reg, flags), full[reg[1]:reg[3], reg[0]:reg[2]])
 
 
+def _guarded_copy(a):
+    """A copy of the 2-D u8 array whose LAST byte is the last byte before a PROT_NONE page: a host-side read of
+    even one byte past the image (e.g. a copy sized by the other image's dimensions) faults instead of passing."""
+    import ctypes
+    import mmap
+    page = mmap.PAGESIZE
+    n = a.size
+    body = (n + page - 1) // page * page
+    m = mmap.mmap(-1, body + page)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc = ctypes.CDLL(None, use_errno=True)
+    assert libc.mprotect(ctypes.c_void_p(base + body), ctypes.c_size_t(page), 0) == 0, ctypes.get_errno()   # PROT_NONE
+    g = np.frombuffer(m, np.uint8, n, body - n).reshape(a.shape)
+    g[...] = a
+    return g, m          # keep m alive
+
+
+def test_left_and_right_pictures_of_different_sizes(ctx):
+    """pkg/camera/output.go:134-162 decodes left.png and right.png independently and the reference copes with a
+    right image of another size: windows clamp to the LEFT image, the right window is walked with the same extent
+    and the loops break where it leaves right.Rect.Max (sad.go:212-218,225-227,231-233).  sadhip_disparity_lr_u8
+    and the three bindings' RunSad / worker do the same -- compared here with the literal restatement run with the
+    right image's own size -- and nothing is read outside the right image (it ends at a PROT_NONE page)."""
+    rng = np.random.default_rng(77)
+    W, H = 200, 96
+    L = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    full = np.roll(L, -5, axis=1) ^ (rng.integers(0, 64, (H, W), dtype=np.uint8) == 0).astype(np.uint8)
+    cases = [(150, 70), (200, 60), (120, 96), (1, 1), (37, 3), (199, 95), (260, 120), (200, 120), (230, 96)]
+    for rw, rh in cases:
+        Rsrc = np.zeros((rh, rw), np.uint8)
+        Rsrc[:min(rh, H), :min(rw, W)] = full[:min(rh, H), :min(rw, W)]
+        if rw > W or rh > H:
+            Rsrc[H:, :] = 201; Rsrc[:, W:] = 202                      # never addressed (right indices <= left indices)
+        R, keep = _guarded_copy(Rsrc)
+        smaller = rw < W or rh < H
+        for block, maxdisp in ((9, 64), (7, 16), (16, 32)):
+            exp = oracle.disparity_literal_lr(L, R, block, maxdisp)
+            got = ctx.disparity_lr(L, R, block, maxdisp)
+            assert np.array_equal(got, exp), (rw, rh, block, maxdisp)
+            # a smaller right image runs the generic kernel (dropped window terms); a larger one is the ordinary job
+            assert capi.last_kernel_kind() == (capi.KIND_GENERIC if smaller else capi.kernel_kind(W, H, block, maxdisp))
+            if not smaller:
+                assert np.array_equal(got, _expect(L, np.ascontiguousarray(R[:H, :W]), block, maxdisp))
+        # regions like the worker's chunks (sad.go:47-101), region-local output
+        for reg in ((0, 0, W, 7), (13, 40, 181, 77), (W - 9, H - 5, W, H)):
+            exp = oracle.disparity_literal_lr(L, R, 9, 64, region=reg)
+            assert np.array_equal(ctx.disparity_lr(L, R, 9, 64, region=reg), exp), (rw, rh, reg)
+        # the Python mirror of the Go API: RunSad and the channel worker
+        assert np.array_equal(sha.despair.RunSad(L, R, 9, 64), oracle.disparity_literal_lr(L, R, 9, 64))
+        inp, outp = sha.despair.SetupConcurrentSAD(2)
+        bands = [(0, y, W, min(y + 17, H)) for y in range(0, H, 17)]
+        for b in bands:
+            inp.send(sha.despair.InputChunk(L, R, b))
+        inp.close()
+        assert np.array_equal(sha.despair.AssembleDisparityMap(outp, (0, 0, W, H), len(bands)), oracle.disparity_literal_lr(L, R, 9, 64))
+        del R, keep
+    # hardware-mirror modes have one image size: a smaller right image is an error there, not a guess
+    with pytest.raises(capi.SadHipError) as e:
+        ctx.disparity_lr(L, np.zeros((50, 50), np.uint8), 15, 64, flags=capi.FLAG_MIRROR_SADC)
+    assert e.value.status == capi.ERR_DIMS
+    with pytest.raises(capi.SadHipError) as e:
+        ctx.disparity_lr(L, np.zeros((50, 50), np.uint8), 9, 64, region=(0, 0, W + 1, H))
+    assert e.value.status == capi.ERR_REGION
+
+
 def test_channel_api_round_trip(ctx):
     """examples/run.stream.go:30-59 shape: long-lived pipeline, row-band chunks, assemble."""
     d = sha.despair
@@ -423,6 +488,74 @@ def test_batch_host_pipeline(ctx):
     assert ctx.disparity_batch([], [], 9, 64) == []
     k_ms, t_ms = ctx.last_timing()
     assert k_ms > 0 and t_ms >= 0
+
+
+def test_page_locked_host_memory_paths(ctx):
+    """sadhip_host_alloc / sadhip_host_register: frames in page-locked memory run as groups of frames per launch with
+    asynchronous linear copies (frames that follow each other in memory as one copy).  Same results as the pageable
+    path on every layout: one contiguous block, scattered frames, a batch that is only partly page-locked (ordinary
+    path), registered numpy memory, the single-frame entry points, the pool."""
+    W, H, B, D = 320, 200, 9, 64
+    n = 19                                                            # not a multiple of the group size (8)
+    pairs = [sha.synth.synth_pair(500 + i, W, H) for i in range(n)]
+    exp = [_expect(l, r, B, D) for l, r in pairs]
+    with capi.HostBuffer(3 * n * W * H) as hb:
+        blk = hb.view((3, n, H, W))
+        for i, (l, r) in enumerate(pairs):
+            blk[0, i], blk[1, i] = l, r
+        blk[2] = 0xEE
+        # 1. one contiguous block per plane: runs of adjacent frames travel as single copies
+        outs = ctx.disparity_batch([blk[0, i] for i in range(n)], [blk[1, i] for i in range(n)], B, D, outs=[blk[2, i] for i in range(n)])
+        assert all(np.array_equal(outs[i], exp[i]) for i in range(n))
+        assert capi.last_kernel_kind() == capi.kernel_kind(W, H, B, D) == capi.KIND_COLWAVE
+        k_ms, t_ms = ctx.last_timing()
+        assert 0 < k_ms <= t_ms
+        # 2. scattered order (no two consecutive frames adjacent), outputs too
+        order = [(7 * i) % n for i in range(n)]
+        blk[2] = 0xEE
+        outs = ctx.disparity_batch([blk[0, i] for i in order], [blk[1, i] for i in order], B, D, outs=[blk[2, i] for i in order])
+        assert all(np.array_equal(blk[2, i], exp[i]) for i in range(n))
+        # 3. outputs in pageable memory: the whole batch takes the ordinary path, same answer
+        outs = ctx.disparity_batch([blk[0, i] for i in range(n)], [blk[1, i] for i in range(n)], B, D)
+        assert all(np.array_equal(outs[i], exp[i]) for i in range(n))
+        # 4. single-frame entry points with page-locked inputs (linear async upload), whole frame and region
+        got = ctx.disparity(blk[0, 3], blk[1, 3], B, D, out=blk[2, 0])
+        assert np.array_equal(got, exp[3])
+        assert np.array_equal(ctx.disparity_region(blk[0, 5], blk[1, 5], B, D, (11, 50, 300, 130)), exp[5][50:130, 11:300])
+        assert np.array_equal(ctx.disparity_lr(blk[0, 6], blk[1, 6][:150, :], B, D),
+                              oracle.disparity_literal_lr(np.ascontiguousarray(blk[0, 6]), np.ascontiguousarray(blk[1, 6][:150, :]), B, D))
+        # 5. strided rows inside page-locked memory (row stride > width)
+        wide = hb.view((3, n, H, W))[0, :2].reshape(2 * H, W)      # reuse: two frames' worth of rows
+        Ls, Rs = pairs[1][0][:, :250], pairs[1][1][:, :250]
+        wide[:H, :250], wide[H:, :250] = Ls, Rs
+        assert np.array_equal(ctx.disparity(wide[:H, :250], wide[H:, :250], B, D), _expect(np.ascontiguousarray(Ls), np.ascontiguousarray(Rs), B, D))
+        # 6. the pool over page-locked frames (two contexts on this GPU)
+        for i, (l, r) in enumerate(pairs):
+            blk[0, i], blk[1, i] = l, r
+        with capi.Pool([0, 0], W, H) as pool:
+            outs = pool.batch([blk[0, i] for i in range(n)], [blk[1, i] for i in range(n)], B, D, outs=[blk[2, i] for i in range(n)])
+            assert all(np.array_equal(outs[i], exp[i]) for i in range(n))
+    # 7. memory the caller owns, page-locked in place
+    own = np.zeros((3, 4, H, W), np.uint8)
+    for i in range(4):
+        own[0, i], own[1, i] = pairs[i]
+    capi.host_register(own)
+    try:
+        outs = ctx.disparity_batch([own[0, i] for i in range(4)], [own[1, i] for i in range(4)], B, D, outs=[own[2, i] for i in range(4)])
+        assert all(np.array_equal(outs[i], exp[i]) for i in range(4))
+    finally:
+        capi.host_unregister(own)
+    # 8. error codes, no crash: unknown pointers, double free
+    l = capi.lib()
+    junk = np.zeros(16, np.uint8)
+    assert l.sadhip_host_free(junk.ctypes.data) == capi.ERR_ARG
+    assert l.sadhip_host_unregister(junk.ctypes.data) == capi.ERR_ARG
+    assert l.sadhip_host_free(None) == capi.ERR_NULL and l.sadhip_host_alloc(0, None) == capi.ERR_NULL
+    import ctypes
+    p = ctypes.c_void_p()
+    assert l.sadhip_host_alloc(0, ctypes.byref(p)) == capi.ERR_ARG
+    assert l.sadhip_host_alloc(4096, ctypes.byref(p)) == capi.OK and p.value
+    assert l.sadhip_host_free(p) == capi.OK and l.sadhip_host_free(p) == capi.ERR_ARG
 
 
 def test_device_resident_batch(ctx):

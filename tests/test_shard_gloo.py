@@ -54,5 +54,7 @@ def test_single_rank_needs_no_process_group():
     import steroscopic_hardware_amd as sha
     assert sha.shard.frame_seeds(0, 1, 3) == [1000, 1001, 1002]
     assert sha.shard.frame_seeds(5, 8, 2) == [1005, 1013]
+    # BASELINE config 4 on 8 GPUs: 1024 pairs in total, 128 per rank, every frame exactly once (bench.py's default split)
+    assert sorted(i for r in range(8) for i in sha.shard.frame_indices(r, 8, 1024 // 8)) == list(range(1024))
     assert sha.shard.broadcast_params(None, 0, 9, 64, torch.device("cpu")) == (9, 64)
     assert sha.shard.max_over_ranks(None, 3.5, torch.device("cpu")) == 3.5

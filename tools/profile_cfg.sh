@@ -4,6 +4,9 @@
 # tools/summarize_cfg.py into profiles/.
 #   tools/profile_cfg.sh <tag> W H BLOCK MAXDISP NFRAMES
 # Output: gpurun_out/prof_<tag>/{trace,pmc_sq,pmc_fetch,pmc_write}/
+# The counter passes sample the disparity kernels ONLY (--kernel-include-regex): bench_cfg.py builds its frames with
+# ~40 torch elementwise launches per pair, and counter collection over all of them is what aborted at 1024 resident
+# pairs in round 2 (PMC_FILTER= (empty) rebuilds that unfiltered run for the record).
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -11,13 +14,16 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+KFILTER=${PMC_FILTER-k_colwave|k_disparity|k_gray|k_sad_windows}
+FARGS=()
+[ -n "$KFILTER" ] && FARGS=(--kernel-include-regex "$KFILTER")
 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/trace.log 2>&1
 echo "[$TAG] trace exit=$? $(tail -1 $OUT/trace.log)"
-timeout -k 10 420 rocprofv3 --kernel-trace --pmc ${PMC_SQ:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES} GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_sq.log 2>&1
-echo "[$TAG] pmc sq exit=$?"
-timeout -k 10 420 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 420 rocprofv3 --kernel-trace "${FARGS[@]}" --pmc ${PMC_SQ:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES} GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_sq.log 2>&1
+echo "[$TAG] pmc sq exit=$? $(grep -c . $OUT/pmc_sq.log) log lines"
+timeout -k 10 420 rocprofv3 --kernel-trace "${FARGS[@]}" --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_fetch.log 2>&1
 echo "[$TAG] pmc fetch exit=$?"
-timeout -k 10 420 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_write.log 2>&1
+timeout -k 10 420 rocprofv3 --kernel-trace "${FARGS[@]}" --pmc GRBM_GUI_ACTIVE WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_write.log 2>&1
 echo "[$TAG] pmc write exit=$?"
 # keep only the disparity kernels' rows of the big CSVs (torch's generator kernels dominate them):
 # gpurun copies back at most 64 MiB
