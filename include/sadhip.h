@@ -78,11 +78,18 @@ extern "C" {
  * (SURVEY.md section 8 f-4, a-10).  Mutually exclusive; block = the models' WIN, maxdisp = MAX_DISP. */
 #define SADHIP_FLAG_MIRROR_SADC   4u /* hardware/sad.c:66-106 (interior only, xr<0 terms skipped) */
 #define SADHIP_FLAG_MIRROR_TESTPY 8u /* hardware/test.py:262-294 compute_disparity_patch (zero padding) */
-#define SADHIP_FLAG_MIRROR_VERILOG 16u /* hardware/compute_SAD.v:62-265 compute_max_disp: the right window slides to
-                                        * LARGER columns (:213), d in [0, maxdisp) EXCLUSIVE (:206-215) and only while the
-                                        * window stays inside the image, strict '<' (:201-204), interior pixels only
-                                        * (border 0); a WIN-row strip of the testbenches (ez_tb.v) gives its result at
-                                        * (x, y) = (col_index + WIN/2, WIN/2) */
+#define SADHIP_FLAG_MIRROR_VERILOG 16u /* the search the Verilog TESTBENCH golden values describe (hardware/mems/exp_disp_n.mem,
+                                        * old_mems/exp_disp.mem, read by ez_tb.v:69-116): the right window slides to LARGER
+                                        * columns, contiguously -- argmin_d sum |L[r][c] - R[r][c+d]| -- d in [0, maxdisp)
+                                        * EXCLUSIVE (compute_SAD.v:206-215) and only while the window stays inside the image,
+                                        * strict '<' (:201-204), interior pixels only (border 0); a WIN-row strip of the
+                                        * testbenches gives its result at (x, y) = (col_index + WIN/2, WIN/2).
+                                        * This is the INTENDED design, not the RTL as written: compute_max_disp shifts in
+                                        * img_block_R[row][col_index + disp_idx + 1] (:213) where a contiguous window needs
+                                        * column col_index + WIN + disp_idx, so from d = 1 on its window re-reads columns it
+                                        * already holds, and it outputs best_disp - (WIN-1) (:219).  The mode reproduces the
+                                        * committed golden files; fixtures regenerated with it describe the intended
+                                        * sliding-window search the RTL is being brought up against. */
 
 typedef struct sadhip_ctx sadhip_ctx;   /* opaque per-device context */
 
@@ -219,7 +226,7 @@ SADHIP_API int sadhip_last_kernel_kind(void);
 
 /* How the fast kernel would run a parameter set (diagnostics / tests; needs no GPU): writes one
  * line per pass, "dbase=<first candidate> count=<candidates> p=<columns per lane> nd=<chunk> nw=<waves>
- * packed=<0|1> extra=<0|1> w16=<0|1> fl=<0|1> lds=<bytes>", into buf (NUL-terminated, truncated to cap).
+ * packed=<0|1> extra=<0|1> w16=<0|1> lds=<bytes>", into buf (NUL-terminated, truncated to cap).
  * Returns the number of passes, 0 when the generic kernel would run, -1 on invalid parameters. */
 SADHIP_API int sadhip_plan_describe(int w, int h, int block, int maxdisp, char* buf, int cap);
 

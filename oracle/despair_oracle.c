@@ -325,7 +325,13 @@ ORACLE_API void oracle_mirror_testpy(const uint8_t *L, const uint8_t *R, int w, 
 /* one WIN x (cols) strip pair, argmin_d sum |L[r][c] - R[r][c+d]| over the   */
 /* first WIN columns of L, d in [0, ndisp), strict '<' (:201-204).            */
 /* Returns best d; *min_sad_out gets the minimum.  (Verilog sign convention:  */
-/* the right window slides to LARGER columns, compute_SAD.v:213.)             */
+/* the right window slides to LARGER columns.)  This is the search the        */
+/* testbench GOLDEN VALUES describe (mems/exp_disp_n.mem = 12 12 15 0F,       */
+/* old_mems/exp_disp.mem = 23 0E 29 31), i.e. the intended contiguous sliding */
+/* window -- NOT the RTL as written, which shifts in                          */
+/* img_block_R[row][col_index + disp_idx + 1] (compute_SAD.v:213; a           */
+/* contiguous window needs column col_index + WIN + disp_idx) and outputs     */
+/* best_disp - (WIN-1) (:219).                                                */
 /* ------------------------------------------------------------------------ */
 ORACLE_API int oracle_mirror_verilog_strip(const uint8_t *L, const uint8_t *R,
                                            int win, int cols, int ndisp, int *min_sad_out)

@@ -1,0 +1,201 @@
+// colwave_plan.hip -- planner of the column-wave kernel: see colwave_plan.h.  Host code only.
+#include "colwave_plan.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+namespace sadhip {
+
+// LDS bytes of one workgroup of a plan (the layout at the top of Cw::run): 2h+3 ring rows and the
+// row of zeros, two row-best buffers, the output LUT.
+size_t plan_lds_bytes(const Plan& pl, int h, int maxdisp)
+{
+  const bool swz = pl.p == 8 && !pl.w16 && pl.nd == 8;
+  const size_t tw = 64 * (size_t)pl.p, rw = tw + (size_t)pl.nw * pl.nd + ((pl.w16 || swz) ? 7 : 3) + 1, roww = tw + rw;
+  return (size_t)(2 * h + 4) * roww * (pl.w16 ? 2 : 4) + (size_t)2 * 72 * pl.p * 4 + (size_t)((maxdisp + 1 + 15) & ~15);
+}
+
+#ifdef SADHIP_TUNING
+int env_int(const char* name, int dflt)
+{
+  struct Entry { const char* name; int value; bool set; };
+  static const auto table = [] {
+    static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
+                                        "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
+                                        "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
+                                        "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE"};
+    std::vector<Entry> t;
+    for (const char* n : names) {
+      const char* e = getenv(n);
+      t.push_back(Entry{n, e ? atoi(e) : 0, e != nullptr});
+    }
+    return t;
+  }();
+  for (const Entry& e : table)
+    if (e.name == name || strcmp(e.name, name) == 0) return e.set ? e.value : dflt;
+  const char* e = getenv(name);                                 // not in the table: read it live
+  return e ? atoi(e) : dflt;
+}
+#endif
+
+// Kernel variant for `count` consecutive candidates: columns per lane P, packed or not, chunk size
+// ND, wave count NW and whether the last wave carries one extra candidate (NW*ND + 1 == count, the
+// usual case: the UI's D is a multiple of 16).  Cost model: a workgroup advances at the pace of
+// its most loaded SIMD, i.e. ceil(NW/4) waves of (per-candidate work * ND + per-wave overhead) per
+// row.  exact: no chunk may run past the last candidate (packed h = 6, 7 masks keys with lane masks
+// that cannot express it).
+//   packed   (h <= 7): P = 4, ND in {4, 8, 12, 16} (h <= 4 also 20, 24; h = 5..7 with two-lane halos);
+//                      P = 8 (h = 5..7, when P = 4 has no plan: exact plans of the lane-mask variants), ND in {4, 8, 12}
+//   unpacked (h = 8; h = 6, 7 without an exact packed plan; SADHIP_TUNE_PK=0): P = 8, ND in {4, 8, 12}
+// Measured on MI355X: for h = 5..7 the P = 4 kernels -- 4..8 waves per workgroup, two to four
+// independent workgroups per CU -- beat the P = 8 ones (8..16 waves, one or two per CU) by 2-15 % although
+// their windows span five lanes instead of three (7.0 against 6.6 instructions per 64 candidates).
+static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int p);
+
+Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
+{
+  const int force_p = env_int("SADHIP_TUNE_P", 0);              // tuning aid: force the columns per lane
+  if (pk && h <= 7 && force_p != 8) {
+    const Plan pl = plan_count_p(h, pk, count, exact, maxdisp, 4);
+    if (pl.nw || force_p == 4 || h <= 4) return pl;
+  }
+  return plan_count_p(h, pk, count, exact, maxdisp, 8);
+}
+
+static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int p)
+{
+  Plan best{0, 0, 0, false, false, false};
+  const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aids: force a chunk size / wave count
+  const int force_nw = env_int("SADHIP_TUNE_NW", 0);
+  long best_cost = 1L << 60;
+  // chunk sizes: P = 4 up to 24; P = 8 up to 12 for the penalty variants (packed h = 5), 8 otherwise --
+  // measured: the lane-mask variants spill at ND 12 (B15 D48: 47 vs 36 us) and the unpacked ones
+  // lose their u16 ring (B16 D48: 41 vs 37 us)
+  const int nd_max = p == 4 ? 24 : ((pk && h <= 5) ? 12 : 8);
+  for (int nd = 4; nd <= nd_max; nd += 4) {
+    if (force_nd && force_nd != nd) continue;
+    for (int nw = 4; nw <= 16; ++nw) {                          // (two-wave workgroups for D <= 48 measured 25-35 % slower)
+      if (force_nw && force_nw != nw) continue;
+      if (p == 4 && nw > 8) continue;                           // measured: 11-16 waves (one workgroup per CU) lose ~10 % to passes of 8 waves
+      if (p == 4 && h > 4 && nd > 16) continue;                 // two-lane halo kernels exist for ND 4, 8, 12, 16
+      if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
+      // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated
+      // for packed h = 7 and unpacked h = 8, chunk size 8, <= 8 waves; unpacked pixels << bitlen(D) must fit)
+      const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
+                       ((pk && h == 7) || (!pk && h >= 8 && maxdisp <= 255));
+      // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
+      const size_t lds_plan = plan_lds_bytes(Plan{p, nd, nw, pk, false, w16}, h, maxdisp);
+      if (lds_plan > (size_t)160 * 1024) continue;
+      const int slots = nw * nd;
+      if (slots + 1 < count) continue;
+      const bool extra = slots + 1 == count;
+      if (exact && !extra && slots != count) continue;
+      if (!extra && slots - nd >= count && nw > 4) continue;    // a whole wave would be idle
+      const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
+      // waves a CU can hold of this plan (LDS; 128 VGPRs = 16 waves for the unpacked kernels): with one
+      // 4-wave workgroup per CU nothing hides its latencies (measured: BlockSize 16, D 16 as 4 waves x 4
+      // candidates on a u32 ring, one workgroup per CU, 26.7 us; as 4 x 8 on the u16 ring, three per CU, 20.5)
+      const long resident = std::min<long>((long)((size_t)160 * 1024 / lds_plan) * nw, pk ? 20 : 16);
+      const long pct = resident <= 4 ? 200 : resident <= 8 ? 118 : 100;
+      const long cost = (long)((nw + 3) / 4) * per_wave * 64 * pct / 100 + nw;    // ties: fewer waves
+      if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra, w16}; }
+    }
+  }
+  return best;
+}
+
+// The whole disparity range [0, D] as one pass, or -- when D+1 candidates do not fit the waves a
+// workgroup may have -- as several full passes of `chunk` candidates plus a last pass for the rest
+// (see CwArgs).
+// Packed first; unpacked when the window SAD does not fit 16 bits (h = 8), when forced, or when a
+// packed h = 6, 7 kernel has no exact plan.  Empty result: the generic kernel runs the job.
+// narrow: the frame is at most D + 2h + 2 wide -- a right-clipped window of a packed variant could
+// meet a missing candidate without its penalty column, so only the unpacked variants (every column
+// penalised) may run.
+static std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow);
+
+const std::vector<Pass>& plan_job(int h, int maxdisp, bool narrow)
+{
+  thread_local int memo_h = -1, memo_d = -1, memo_n = -1;
+  thread_local std::vector<Pass> memo;
+  if (h != memo_h || maxdisp != memo_d || (int)narrow != memo_n) {
+    memo = plan_job_uncached(h, maxdisp, narrow); memo_h = h; memo_d = maxdisp; memo_n = narrow;
+  }
+  return memo;
+}
+
+static std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
+{
+  std::vector<Pass> passes;
+  if (h < 1 || h > 15 || maxdisp < 1) return passes;
+  for (int variant = (h <= 7 && !narrow && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; variant < 2; ++variant) {
+    const bool pk = variant == 0;
+    if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
+    // unpacked keys ((2h+1)^2*255 << bitlen(D)) must stay below the 2^27 penalty
+    const int b1 = 2 * h + 1, ksh = 32 - __builtin_clz((unsigned)maxdisp);
+    if (!pk && ((long long)b1 * b1 * 255 << ksh) >= (1LL << 27)) break;
+    const bool exact = pk && h > 5;
+    // full passes: 8 waves of ND 16 (P 4) / 16 waves of ND 8 (P 8); two-lane halos: 8 waves of ND 8
+    const int chunk = env_int("SADHIP_TUNE_CHUNK", h <= 8 ? 128 : 64);
+    passes.clear();
+    int base = 0, rem = maxdisp + 1;
+    while (rem > 0) {
+      Plan pl = plan_count(h, pk, rem, exact, maxdisp);
+      if (pl.nw) { passes.push_back(Pass{pl, base}); rem = 0; break; }
+      if (rem <= chunk) break;                                  // no plan for the rest
+      pl = plan_count(h, pk, chunk, true, maxdisp);
+      if (!pl.nw) break;
+      passes.push_back(Pass{pl, base});
+      base += chunk; rem -= chunk;
+    }
+    if (rem == 0) return passes;
+  }
+  passes.clear();
+  return passes;
+}
+
+// ---- strip count of a launch ---------------------------------------------------------------------
+// base = workgroups per strip layer (tiles x frames), rows = output rows, h2 = 2h warm-up rows per strip,
+// cus = compute units, per_cu = workgroups of this kernel a CU holds.  Cost of ns strips of th rows:
+//   work per workgroup  = th + h2 + 4 rows (4: set-up, ring fill, first barrier)
+//   k = ceil(base*ns / cus) workgroups on the busiest CU (round-robin dispatch)
+//   k <= per_cu: one round; a workgroup with fewer neighbours runs faster -- measured single 1080p pairs:
+//                1 / 2 / 5 resident workgroups take 0.42 / 0.55 / 1.0 of the full-occupancy time per row
+//                -> duration factor 0.27 + 0.73 * k / per_cu
+//   k >  per_cu: between base*ns / (cus*per_cu) rounds (perfect balance) and ceil(k / per_cu) (the busiest CU): their mean
+//   + 0.15 of a workgroup's duration for the tail in both cases: workgroups are not equally long (the
+//   leftmost tiles mask keys, CUs differ), and the longer they are the longer the chip waits for the last
+//   one (measured: 128 1080p pairs as 1 / 4 strips 27.7 / 24.2 us per pair; config 5 with 16 pairs as
+//   1 / 2 / 4 / 6 rounds 228 / 218 / 213 / 210)
+long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_rows)
+{
+  const long max_strips = std::max<long>(1, (rows + min_rows - 1) / min_rows);
+  const double slots = (double)cus * per_cu;
+  double best = 1e300;
+  long best_ns = 1;
+  for (long ns = 1; ns <= max_strips; ++ns) {
+    const long th = (rows + ns - 1) / ns;
+    if ((rows + th - 1) / th != ns) continue;                   // this strip height gives fewer strips: counted there
+    const long w = base * ns, k = (w + cus - 1) / cus;
+    const double whole = (double)((k + per_cu - 1) / per_cu);   // rounds on the busiest CU
+    const double t = (k <= per_cu ? 0.27 + 0.73 * (double)k / per_cu : 0.5 * ((double)w / slots + whole)) + 0.15;
+    const double cost = t * (double)(th + h2 + 4);
+    if (cost < best * 0.999) { best = cost; best_ns = ns; }     // ties: fewer strips
+  }
+  return best_ns;
+}
+
+int cu_count()
+{
+  thread_local int dev_cached = -1, cus = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return cus;
+  if (dev != dev_cached) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    dev_cached = dev;
+  }
+  return cus;
+}
+
+}  // namespace sadhip

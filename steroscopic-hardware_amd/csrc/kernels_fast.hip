@@ -1,53 +1,9 @@
-// kernels_fast.hip -- "column-wave" SAD disparity kernel for gfx950 (MI355X).
-//
-// Function computed (bit-exact with pkg/despair/sad.go:55-94 + :205-244, closed form of
-// SURVEY.md section 8 a-1):   out(x,y) = scale(argmin_{d in [0,min(D,max(0,x-h))]} SAD(x,y,d)),
-// first minimum wins, windows clipped to the image.
-//
-// Mapping (why it looks like this -- measured on MI355X, tools/ubench/*.hip):
-//   * the path is integer-VALU bound: v_sad_*/min3/DPP/perm ops cost ~4.3 SIMD-cycles per
-//     wave-instruction, plain v_add/v_sub ~2.5, v_qsad_pk_u16_u8 is quarter rate; one LDS dword per
-//     lane costs as much as two such VALU ops.  So: every |L-R| is one SAD instruction with the
-//     accumulate folded in, everything else is adds/subs, operands stay in registers.
-//   * lane l of a wave owns P (4 or 8) adjacent columns; a wave owns ND consecutive disparities
-//     for its 64*P columns; the NW waves of a workgroup split the disparity range of one tile.
-//     NW is a multiple of 4 with equal work per wave whenever D allows: the four SIMDs of a CU
-//     issue oldest-workgroup-first, so a workgroup whose waves sit 2,2,1,1 on them runs at the pace
-//     of the doubly loaded SIMDs and a quarter of the CU idles (tools/ubench/block_bench.hip:
-//     6 waves per workgroup cost 1.29x, 4 / 8 / 12 cost 1.00x).  The UI's disparity ranges are
-//     multiples of 16, i.e. 16k+1 candidates: the last wave carries the odd one out.
-//   * vertical: each lane keeps the column sums of its (column, disparity) pairs in registers and
-//     slides them down the strip: + |L-R| of the row entering the window, - |L-R| of the row
-//     leaving it.  Packed variant (window SAD < 65536): two adjacent disparities share a register
-//     as u16 halves (v_sad_u8 -> low half, v_sad_hi_u8 -> high half); unpacked: u32 + v_sad_u32.
-//   * horizontal: the (2h+1)-wide window sum = in-lane prefix sums + 2h values fetched from the
-//     two neighbour lanes with v_add_u32_dpp wave_shr:1 / wave_shl:1 (no LDS).
-//   * argmin: strict-'<' first minimum (sad.go:79) = unsigned min of keys (SAD << 16) | d
-//     (v_min3_u32).  Packed: v_lshl_or_b32 / v_perm_b32 build the two keys of a register.
-//     Unpacked: pixels are pre-scaled by 2^KSH and every window contains exactly one column whose
-//     sum starts at d, so the window sum IS the key.
-//   * waves merge their per-pixel minima with ds_min_u32 into a row buffer in LDS; after the one
-//     barrier per row every wave maps its 1/NW share of the keys -> d -> best*255/D (LUT) and
-//     stores u8.
-//   * image rows stream through an LDS ring (2h+3 rows, one u32 per pixel); every wave loads its
-//     1/NW share of the next row before its arithmetic and lands it in the ring afterwards, so the
-//     load latency hides behind a whole row of VALU work and all waves stay symmetric (a dedicated
-//     streaming wave made one SIMD the pacemaker, see above).
-//     ND is a multiple of 4 and the R part of a ring row is offset so that every
-//     lane's operands are 16-byte aligned: all operand reads are ds_read_b128, bank-conflict free
-//     at a lane stride of 16 bytes (ds_read_b32 at that stride was a 4-way conflict: 72 % of LDS
-//     cycles in the first version).  Variants whose u32 ring would leave room for one workgroup
-//     per CU only keep u16 pixels instead (W16).
-//   * missing candidates (d > x-h at the left image edge, d > D in a ragged last chunk) are removed
-//     by the START VALUES of the column sums (penalties that survive the sliding updates), not by
-//     masking keys row after row; packed h = 6, 7, where a penalty does not fit u16, masks keys
-//     with 64-bit lane masks held in SGPRs (one v_cndmask_b32 per key, leftmost tile only).
-//   * BlockSize 18..31: the window reaches into the lane after the neighbour (two DPP hops).
-//   * D+1 beyond 16 waves' worth: several launches over candidate ranges, a u32 key per pixel
-//     travelling between them (plan_job / launch_fast at the end of this file).
-#include "sadhip_kernels.h"
+// kernels_fast.hip -- instantiations, launch geometry and launch table of the column-wave kernel
+// (device code: colwave_kernel.h; planner: colwave_plan.{h,hip}).  Entry points of this file (sadhip_kernels.h):
+// fast_supported, describe_fast, launch_fast.
+#include "colwave_kernel.h"
+#include "colwave_plan.h"
 #include <algorithm>
-#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -57,1315 +13,11 @@ namespace sadhip {
 
 namespace {
 
-struct CwArgs {
-  Job j;
-  int nw;          // waves per workgroup (disparity chunks), 4..16
-  int xw;          // wave that also owns candidate nw*ND (the 16k+1-th), or -1
-  int ksh;         // bits of the disparity field of a key (unpacked: 2^ksh > maxdisp; packed: 16)
-  int pixshift;    // left shift applied to pixels landing in LDS (unpacked: ksh; packed: 0)
-  int dpad;        // columns of R kept left of the tile (== 3 mod 4, >= largest candidate)
-  int tx0;         // origin of tile 0 (<= 0, == w mod P)
-  int tile0;       // first tile index launched (blockIdx.y + tile0)
-  int nstrips;     // strips per frame: blockIdx.x = strip + nstrips * frame
-  int th;          // output rows per strip
-  int shl, shr;    // per-wave share of a ring row: L elements (= output pixels), R elements
-  // Disparity ranges wider than one workgroup can hold run as several passes (launches) over
-  // candidates [dbase, dbase + nw*ND (+1)): a pass merges its per-pixel keys with the keys of the
-  // passes before it (kin) and hands them on (kout); the last pass writes the u8 output.
-  int dbase;
-  const unsigned* kin;     // keys so far, or nullptr (first pass)
-  unsigned* kout;          // where to leave the keys, or nullptr (last pass: write the output)
-  int kw;                  // u32 per key row (= x1 - x0); key of (f, y, x) at (f*rows + y-y0)*kw + x-x0
-#ifdef SADHIP_STAMPS
-  // stamps build only (make stamps): per-wave sums of shader-clock ticks spent in the five phases of a row
-  // step (update, reduce, land, output, barrier wait) + the step count, at stamps[(workgroup*16 + wave)*8 + k]
-  unsigned long long* stamps;
-#endif
-};
-
-constexpr unsigned KEY_INVALID = 0xffffffffu;
-// Compile-time switches that rebuild two measured alternatives, never set by the Makefile:
-//   -DSADHIP_X_BUFLOAD   raw buffer loads for the unpacked variants' row fetch too (slower: register allocation)
-//   -DSADHIP_X_NORECOMP  row-share state held across the row loop instead of re-derived per step (spills)
-#ifdef SADHIP_X_BUFLOAD
-constexpr bool X_BUFLOAD = true;
-#else
-constexpr bool X_BUFLOAD = false;
-#endif
-#ifdef SADHIP_X_NORECOMP
-constexpr bool X_NORECOMP = true;
-#else
-constexpr bool X_NORECOMP = false;
-#endif
-
-// |a - b| + acc in one instruction, in place.  Inline asm: left to itself hipcc canonicalises the
-// C++ form into v_max_u32 + v_min_u32 + v_sub/v_add3 (3 ops) inside the unrolled update.
-__device__ __forceinline__ void sad_acc(unsigned& acc, unsigned a, unsigned b)
-{
-  asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-// c_i -= |l - r_i| for four disparities in ONE asm statement.  hipcc pads every asm boundary
-// whose registers the next instruction touches with an s_nop, and on this chip an s_nop costs a
-// full issue slot (tools/ubench/block_bench.hip: 46 such pads were 24 % of the update block);
-// four per statement leaves one pad per four candidates and keeps the sad -> sub pairs apart.
-__device__ __forceinline__ void sad_sub4(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
-                                         unsigned l, unsigned r0, unsigned r1, unsigned r2, unsigned r3)
-{
-  unsigned t0, t1, t2, t3;
-  asm("v_sad_u32 %4, %8, %9, 0\n\t"
-      "v_sad_u32 %5, %8, %10, 0\n\t"
-      "v_sad_u32 %6, %8, %11, 0\n\t"
-      "v_sad_u32 %7, %8, %12, 0\n\t"
-      "v_sub_u32 %0, %0, %4\n\t"
-      "v_sub_u32 %1, %1, %5\n\t"
-      "v_sub_u32 %2, %2, %6\n\t"
-      "v_sub_u32 %3, %3, %7"
-      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "v"(l), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
-}
-// c_i -= |l_i - r_i| for four columns of one disparity.
-__device__ __forceinline__ void sad_sub4x(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
-                                          unsigned l0, unsigned l1, unsigned l2, unsigned l3,
-                                          unsigned r0, unsigned r1, unsigned r2, unsigned r3)
-{
-  unsigned t0, t1, t2, t3;
-  asm("v_sad_u32 %4, %8, %12, 0\n\t"
-      "v_sad_u32 %5, %9, %13, 0\n\t"
-      "v_sad_u32 %6, %10, %14, 0\n\t"
-      "v_sad_u32 %7, %11, %15, 0\n\t"
-      "v_sub_u32 %0, %0, %4\n\t"
-      "v_sub_u32 %1, %1, %5\n\t"
-      "v_sub_u32 %2, %2, %6\n\t"
-      "v_sub_u32 %3, %3, %7"
-      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
-}
-// Byte-lane forms of the two helpers above (triple-column operands, Cw::TR3: three pixel bytes per word).
-__device__ __forceinline__ void sad8_acc(unsigned& acc, unsigned a, unsigned b)
-{
-  asm("v_sad_u8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void sad8_sub4x(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
-                                           unsigned l0, unsigned l1, unsigned l2, unsigned l3,
-                                           unsigned r0, unsigned r1, unsigned r2, unsigned r3)
-{
-  unsigned t0, t1, t2, t3;
-  asm("v_sad_u8 %4, %8, %12, 0\n\t"
-      "v_sad_u8 %5, %9, %13, 0\n\t"
-      "v_sad_u8 %6, %10, %14, 0\n\t"
-      "v_sad_u8 %7, %11, %15, 0\n\t"
-      "v_sub_u32 %0, %0, %4\n\t"
-      "v_sub_u32 %1, %1, %5\n\t"
-      "v_sub_u32 %2, %2, %6\n\t"
-      "v_sub_u32 %3, %3, %7"
-      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
-}
-// ---- packed variant: one register holds the column sums of two adjacent disparities as u16 halves.
-// Pixels in LDS are plain zero-extended bytes, so v_sad_u8 / v_sad_hi_u8 (|a-b| over 4 byte lanes,
-// result added to the low / high half of the accumulator) are exact single-pixel differences.
-// Two registers (four candidates) per asm statement, independent chains interleaved.
-__device__ __forceinline__ void pk_sad_in2(unsigned& c0, unsigned& c1, unsigned l,
-                                           unsigned re0, unsigned ro0, unsigned re1, unsigned ro1)
-{
-  asm("v_sad_u8 %0, %2, %3, %0\n\t"
-      "v_sad_u8 %1, %2, %5, %1\n\t"
-      "v_sad_hi_u8 %0, %2, %4, %0\n\t"
-      "v_sad_hi_u8 %1, %2, %6, %1"
-      : "+v"(c0), "+v"(c1) : "v"(l), "v"(re0), "v"(ro0), "v"(re1), "v"(ro1));
-}
-__device__ __forceinline__ void pk_sad_out2(unsigned& c0, unsigned& c1, unsigned l,
-                                            unsigned re0, unsigned ro0, unsigned re1, unsigned ro1)
-{
-  unsigned t0, t1;
-  asm("v_sad_u8 %2, %4, %5, 0\n\t"
-      "v_sad_u8 %3, %4, %7, 0\n\t"
-      "v_sad_hi_u8 %2, %4, %6, %2\n\t"
-      "v_sad_hi_u8 %3, %4, %8, %3\n\t"
-      "v_sub_u32 %0, %0, %2\n\t"
-      "v_sub_u32 %1, %1, %3"
-      : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1) : "v"(l), "v"(re0), "v"(ro0), "v"(re1), "v"(ro1));
-}
-// Same for four registers (eight candidates): the temporaries of consecutive statements share
-// registers and hipcc pads that write-after-write across asm boundaries with an s_nop (a full issue
-// slot here), so fewer, larger statements.
-__device__ __forceinline__ void pk_sad_out4(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned l,
-                                            unsigned re0, unsigned ro0, unsigned re1, unsigned ro1,
-                                            unsigned re2, unsigned ro2, unsigned re3, unsigned ro3)
-{
-  unsigned t0, t1, t2, t3;
-  asm("v_sad_u8 %4, %8, %9, 0\n\t"
-      "v_sad_u8 %5, %8, %11, 0\n\t"
-      "v_sad_u8 %6, %8, %13, 0\n\t"
-      "v_sad_u8 %7, %8, %15, 0\n\t"
-      "v_sad_hi_u8 %4, %8, %10, %4\n\t"
-      "v_sad_hi_u8 %5, %8, %12, %5\n\t"
-      "v_sad_hi_u8 %6, %8, %14, %6\n\t"
-      "v_sad_hi_u8 %7, %8, %16, %7\n\t"
-      "v_sub_u32 %0, %0, %4\n\t"
-      "v_sub_u32 %1, %1, %5\n\t"
-      "v_sub_u32 %2, %2, %6\n\t"
-      "v_sub_u32 %3, %3, %7"
-      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "v"(l), "v"(re0), "v"(ro0), "v"(re1), "v"(ro1), "v"(re2), "v"(ro2), "v"(re3), "v"(ro3));
-}
-__device__ __forceinline__ unsigned from_left(unsigned v)     // lane l <- lane l-1 (lane 0: 0)
-{
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);    // wave_shr:1 bound_ctrl:0
-}
-__device__ __forceinline__ unsigned from_right(unsigned v)    // lane l <- lane l+1 (lane 63: 0)
-{
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);    // wave_shl:1 bound_ctrl:0
-}
-
-// key where the lane's bit of a 64-bit lane mask (SGPR pair) is set, else KEY_INVALID: one
-// v_cndmask_b32 with the mask as its scalar operand -- no v_cmp, no VCC round trip.
-__device__ __forceinline__ unsigned sel_lanes(unsigned long long mask, unsigned key)
-{
-  unsigned r;
-  asm("v_cndmask_b32 %0, -1, %1, %2" : "=v"(r) : "v"(key), "s"(mask));
-  return r;
-}
-// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also emits
-// s_waitcnt vmcnt(0): every wave would then sit at every row barrier until the output bytes it has
-// just stored are acknowledged (a full memory round trip per row).  Nothing depends on them;
-// hipcc places the vmcnt wait of the row loads at their use by itself.  "memory" keeps the
-// compiler from moving LDS accesses across.
-__device__ __forceinline__ void wg_barrier()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int P, int ND, int H, bool PK, bool W16 = false, bool FL = false, bool TR = false>
-struct Cw {                                         // P columns per lane: 4 (packed, h <= 7; two-lane halos from h = 5) or 8 (h <= 15)
-  // FL: "fast-run float" variant of the unpacked layout (P = 8, ND = 8, h = 4..7).  Measured on MI355X
-  // (tools/ubench/valu_mix.hip, valu_rates2.hip): a fast-class instruction (v_add/v_sub_f32, also
-  // with a |x| source modifier) costs ~2.3 SIMD-cycles only inside a RUN of fast-class instructions;
-  // alone between slow-class ones (v_sad_*, DPP, v_min*, v_perm, ...) it costs the same ~4.2 as they do.
-  // Here every pixel and column sum is an f32 holding an exact small integer: |L-R| is v_sub_f32 +
-  // v_add_f32 |t| (two fast ops, long runs), the horizontal prefix / suffix chains are fast runs,
-  // the tie-break index rides in the fraction of the sums (key-in-sum, below), so the only slow-class
-  // work left per candidate is 1 DPP add per window and half a v_min3_f32.
-  static_assert(!FL || (!PK && !W16 && P == 8 && ND == 8 && H >= 4 && H <= 7), "float variant: P 8, ND 8, h 4..7");
-  // PK: column sums of disparity pairs packed as u16 halves (window SAD < 65536, i.e. h <= 7)
-  static_assert(!PK || (H <= 7 && ND % 4 == 0), "packed sums need (2h+1)^2 * 255 < 65536");
-  static constexpr int NC = PK ? ND / 2 : ND;       // accumulator registers per column
-  static_assert(P == 4 || P == 8, "operand reads are whole ds_read_b128");
-  static_assert(H >= 1 && H <= 2 * P - 1, "halo must fit in the two neighbour lanes on each side");
-  // two-lane halos (P < h): the unpacked variants, and packed P = 4 for h = 5..7 (see plan_count)
-  static_assert(H <= P || !PK || P == 4, "packed two-lane halos: P = 4 only");
-  static_assert(ND % 4 == 0, "ND must keep every lane's R operands 16-byte aligned");
-  static constexpr int TW = 64 * P;                 // columns per tile
-  static constexpr int OL = P * ((H + P - 1) / P);  // first output column inside the tile
-  static constexpr int STEP = TW - 2 * OL;          // output columns per tile
-  static constexpr int B1 = 2 * H + 1;              // window width
-  static constexpr int NB = 2;                      // row-best buffers: one being filled, one being drained
-  // A row buffer holds the key of column p of lane l at p*RBP + l: the P ds_min_u32 of a wave then
-  // touch consecutive dwords (at l*P + p all 64 lanes hit 4 (P = 8) or 8 banks: 16-/8-way conflicts,
-  // two thirds of the LDS cycles of the P = 8 variants), and pitch 72 keeps the output pass, which
-  // walks the pixels in image order, at two-way.
-  static constexpr int RBP = 72;
-  static constexpr int RBW = P * RBP;               // u32 per row buffer
-  static constexpr int NR = 2 * H + 3;              // ring rows: window + the leaving row + the landing row
-  static constexpr int NRV = P + ND;                // R values a lane loads per row (last one unused)
-  static constexpr int MAXL = P / 4;                // ring-row L elements per lane (>= 4 waves share a row)
-  // W16: ring pixels are u16 (two per dword) instead of u32 -- half the LDS per workgroup, one
-  // v_and / v_lshrrev more per operand.  For the variants whose ring (2h+4 rows of 1100 pixels)
-  // otherwise leaves room for one workgroup per CU: P = 8, h >= 7.
-  static_assert(!W16 || (P == 8 && ND == 8), "u16 ring: whole 16-byte reads need P and ND multiples of 8");
-  using Px = typename std::conditional<W16, unsigned short, unsigned>::type;
-  // SWZ: quad-swizzled ring rows for the u32 ring of the P = 8, ND = 8 variants.  A lane's operands
-  // are 8 (L) / 16 (R) consecutive pixels = 32-byte lane stride: as ds_read_b128 that is a 2-way bank
-  // conflict (lanes l and l+8 of one 16-lane service group hit the same banks; 45 % of the LDS cycles
-  // of config 5 were conflict cycles, profiles/r02_c5.md).  Each part (L, R) of a ring row is
-  // therefore stored as two halves: quads (4 pixels) with even index in the first half, odd ones in
-  // the second, so that every ds_read_b128 of a lane's operand set sees a 16-byte lane stride again.
-  static constexpr bool SWZ = (P == 8) && !W16 && (ND == 8);
-  static constexpr int XOFF = (W16 || SWZ) ? 7 : 3;  // dpad = nw*ND + XOFF keeps every lane's R operands 16-byte aligned (SWZ: on an even quad)
-  // physical position of logical pixel e within a part of len pixels (len % 8 == 0), and its inverse
-  static __device__ __forceinline__ int phys(int e, int len)
-  {
-    return SWZ ? ((((e >> 3) << 2) | (e & 3)) + ((e >> 2) & 1) * (len >> 1)) : e;
-  }
-  static __device__ __forceinline__ int logical(int f, int len)
-  {
-    if constexpr (!SWZ) return f;
-    const int hl = len >> 1, hi = f >= hl ? 1 : 0, t = f - hi * hl;
-    return ((t >> 2) << 3) | (hi << 2) | (t & 3);
-  }
-  struct Src { const Px* a; const Px* b; };           // operand block of a lane: even quads at a, odd quads at b (SWZ); else all at a
-  static constexpr int MAXR = (TW + 4 * ND + 8 + 255) / 256;   // ... R elements per lane
-  static constexpr bool NEED_MASK = PK && H > 5;    // packed h = 6, 7: 2*(2h+1)^2*255 does not fit u16
-  // TR3: "triple-column" form of the packed P = 4 variants whose window width is a multiple of three
-  // (BlockSize 9: h = 4, and BlockSize 3: h = 1).  v_sad_u8 sums FOUR byte lanes, and the plain form
-  // uses one of them.  Here a ring word of column c holds the pixels c, c+1, c+2 as its three low
-  // bytes, so the same instruction accumulates T(x, d) = the column sums of x, x+1, x+2 together, and
-  // the (2h+1)-wide window of pixel x is T(x-h) + T(x-h+3) + ... : for h = 4 two additions per column
-  // (seven of eight as DPP adds pulling from a neighbour lane) instead of the prefix sums + suffix
-  // differences + two DPP adds of the plain form -- 8 instructions per register instead of 13; for
-  // h = 1 the window IS T(x-1).  Same sums, same keys, same penalties per window (init_sum below).
-  // At the right image edge the form is wrong: the register of column w-2 (w-1) would also sum |0 - R| of
-  // the columns w (w, w+1), which a clipped window of the reference does not contain -- R(x-d) is a real
-  // pixel there, only L is outside the image.  (At the left edge both are outside: |0 - 0|.)  So a
-  // workgroup whose tile holds the columns w-2, w-1 runs the plain form (k_colwave picks per workgroup);
-  // TR is set for the other workgroups of the BlockSize-9 kernels only.  (BlockSize 3, whose window IS one
-  // triple, measured slower in this form: more load traffic per streamed pixel for no arithmetic saved
-  // that its small horizontal pass had not saved already.)
-  static constexpr bool TR3 = TR;
-  static_assert(!TR || (PK && P == 4 && !W16 && !FL && H == 4), "triple-column form: packed P = 4, h = 4");
-  static constexpr int NM = ND + P;                 // lane masks: one per (candidate - column), see run()
-  // Mask k is "lanes >= max(0, floor((T0 + k) / P))" for a wave-uniform T0: consecutive k share their
-  // mask P at a time, so a wave holds only NMB distinct masks plus one carry bit per residue k % P, and
-  // the mask of a compile-time k is a scalar select between two neighbours (SALU: no vector issue slot,
-  // no VGPR).  Round 2's first form kept all NM masks in SGPR pairs: 32-40 SGPRs, 13-25 of them parked
-  // in VGPR lanes by the compiler.
-  static constexpr int NMB = (NM - 1) / P + 2;
-  struct Masks {
-    unsigned long long mb[NMB];
-    unsigned carry;                                   // bit r: (r + T0 mod P) >= P
-    __device__ __forceinline__ unsigned long long at(int k) const
-    {
-      const int i = k / P;
-      unsigned long long a = mb[i], b = mb[i + 1];
-      asm volatile("" : "+s"(a), "+s"(b));            // two scalars selected HERE: not "mb[i + bit]" (array goes to scratch), not hoisted out of the row loop (40 SGPRs again)
-      return ((carry >> (k % P)) & 1u) ? b : a;
-    }
-  };
-
-  // N ring pixels starting at a 16-byte aligned element -> one u32 register each.
-  template <int N>
-  static __device__ __forceinline__ void load_px(Src src, unsigned (&out)[N])
-  {
-    const uint4* s4 = reinterpret_cast<const uint4*>(src.a);
-    if constexpr (W16) {
-      static_assert(N % 8 == 0, "");
-      // the mask lives in a VGPR: v_and_b32 with the 32-bit literal 0xffff is a slow-class instruction
-      // (4.2 cycles), with a register operand it is fast-class (2.3 in a run) -- tools/ubench/valu_rates.hip
-      unsigned lo16 = 0xffffu;
-      asm("" : "+v"(lo16));
-#pragma unroll
-      for (int m = 0; m < N / 8; ++m) {
-        const uint4 v = s4[m];
-        out[8 * m] = v.x & lo16; out[8 * m + 1] = v.x >> 16; out[8 * m + 2] = v.y & lo16; out[8 * m + 3] = v.y >> 16;
-        out[8 * m + 4] = v.z & lo16; out[8 * m + 5] = v.z >> 16; out[8 * m + 6] = v.w & lo16; out[8 * m + 7] = v.w >> 16;
-      }
-    } else {
-      static_assert(N % 4 == 0, "");
-      const uint4* t4 = reinterpret_cast<const uint4*>(src.b);
-#pragma unroll
-      for (int m = 0; m < N / 4; ++m) {
-        const uint4 v = SWZ ? ((m & 1) ? t4[m >> 1] : s4[m >> 1]) : s4[m];
-        out[4 * m] = v.x; out[4 * m + 1] = v.y; out[4 * m + 2] = v.z; out[4 * m + 3] = v.w;
-      }
-    }
-  }
-
-  // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
-  // lin/lout: this lane's P L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
-  static __device__ __forceinline__ void update_columns(unsigned (&C)[P][NC], Src lin, Src rin, Src lout, Src rout)
-  {
-    if constexpr (FL) {
-      {
-        unsigned li[P], ri[NRV];
-        load_px(lin, li);
-        load_px(rin, ri);
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-          for (int q = 0; q < ND; ++q)
-            C[p][q] = __float_as_uint(__uint_as_float(C[p][q]) + __builtin_fabsf(__uint_as_float(li[p]) - __uint_as_float(ri[p + ND - 1 - q])));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        unsigned lo[P], ro[NRV];
-        load_px(lout, lo);
-        load_px(rout, ro);
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-          for (int q = 0; q < ND; ++q)
-            C[p][q] = __float_as_uint(__uint_as_float(C[p][q]) - __builtin_fabsf(__uint_as_float(lo[p]) - __uint_as_float(ro[p + ND - 1 - q])));
-      }
-      return;
-    }
-    {
-      unsigned li[P], ri[NRV];
-      load_px(lin, li);
-      load_px(rin, ri);
-      if constexpr (PK) {
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-          for (int r = 0; r < NC; r += 2)                   // candidates q = 2r .. 2r+3
-            pk_sad_in2(C[p][r], C[p][r + 1], li[p], ri[p + ND - 1 - 2 * r], ri[p + ND - 2 - 2 * r],
-                       ri[p + ND - 3 - 2 * r], ri[p + ND - 4 - 2 * r]);
-      } else {
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-          for (int q = 0; q < ND; ++q) sad_acc(C[p][q], li[p], ri[p + ND - 1 - q]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);                    // keep the two operand sets from overlapping
-    {
-      unsigned lo[P], ro[NRV];
-      load_px(lout, lo);
-      load_px(rout, ro);
-      if constexpr (PK) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-#pragma unroll
-          for (int r = 0; r + 4 <= NC; r += 4)
-            pk_sad_out4(C[p][r], C[p][r + 1], C[p][r + 2], C[p][r + 3], lo[p],
-                        ro[p + ND - 1 - 2 * r], ro[p + ND - 2 - 2 * r], ro[p + ND - 3 - 2 * r], ro[p + ND - 4 - 2 * r],
-                        ro[p + ND - 5 - 2 * r], ro[p + ND - 6 - 2 * r], ro[p + ND - 7 - 2 * r], ro[p + ND - 8 - 2 * r]);
-          if constexpr (NC % 4 != 0) {
-            constexpr int r = NC - 2;
-            pk_sad_out2(C[p][r], C[p][r + 1], lo[p], ro[p + ND - 1 - 2 * r], ro[p + ND - 2 - 2 * r],
-                        ro[p + ND - 3 - 2 * r], ro[p + ND - 4 - 2 * r]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-          for (int q = 0; q < ND; q += 4)
-            sad_sub4(C[p][q], C[p][q + 1], C[p][q + 2], C[p][q + 3], lo[p], ro[p + ND - 1 - q],
-                     ro[p + ND - 2 - q], ro[p + ND - 3 - q], ro[p + ND - 4 - q]);
-      }
-    }
-  }
-
-  // The wave that owns the odd candidate dx = nw*ND (16k+1 candidates, see plan_job) slides its
-  // column sums here: lin/rxin point at this lane's L pixels and at the 16-byte aligned block whose
-  // element XOFF is R column x0 - dx.  Pixels are plain bytes (packed) or pre-shifted (unpacked):
-  // v_sad_u32 accumulates the right thing in both.
-  static __device__ __forceinline__ void extra_update(unsigned (&CX)[P][1], Src lin, Src rxin, Src lout, Src rxout)
-  {
-    constexpr int NX = XOFF == 7 ? 16 : P + 4;            // elements XOFF .. XOFF+P-1 are used
-    if constexpr (FL) {
-      {
-        unsigned li[P], ri[NX];
-        load_px(lin, li);
-        load_px(rxin, ri);
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-          CX[p][0] = __float_as_uint(__uint_as_float(CX[p][0]) + __builtin_fabsf(__uint_as_float(li[p]) - __uint_as_float(ri[p + XOFF])));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        unsigned lo[P], ro[NX];
-        load_px(lout, lo);
-        load_px(rxout, ro);
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-          CX[p][0] = __float_as_uint(__uint_as_float(CX[p][0]) - __builtin_fabsf(__uint_as_float(lo[p]) - __uint_as_float(ro[p + XOFF])));
-      }
-      return;
-    }
-    {
-      unsigned li[P], ri[NX];
-      load_px(lin, li);
-      load_px(rxin, ri);
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        if constexpr (TR3) sad8_acc(CX[p][0], li[p], ri[p + XOFF]);
-        else sad_acc(CX[p][0], li[p], ri[p + XOFF]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      unsigned lo[P], ro[NX];
-      load_px(lout, lo);
-      load_px(rxout, ro);
-#pragma unroll
-      for (int p = 0; p < P; p += 4) {
-        if constexpr (TR3)
-          sad8_sub4x(CX[p][0], CX[p + 1][0], CX[p + 2][0], CX[p + 3][0], lo[p], lo[p + 1], lo[p + 2], lo[p + 3],
-                     ro[p + XOFF], ro[p + XOFF + 1], ro[p + XOFF + 2], ro[p + XOFF + 3]);
-        else
-          sad_sub4x(CX[p][0], CX[p + 1][0], CX[p + 2][0], CX[p + 3][0], lo[p], lo[p + 1], lo[p + 2], lo[p + 3],
-                    ro[p + XOFF], ro[p + XOFF + 1], ro[p + XOFF + 2], ro[p + XOFF + 3]);
-      }
-    }
-  }
-
-  // ---- horizontal window sums + key minimum for one row --------------------------------------
-  // Per disparity q: stage A = in-lane prefix sums ps[] and the suffix sums the right neighbour
-  // needs; stage B = window sums (DPP adds pulling from both neighbour lanes) folded into best[].
-  // A DPP operand must be written >= 2 instructions before the DPP op reads it, or the compiler
-  // pads with s_nop (a full issue slot each here): stage A ends with the suffix subtractions the
-  // DPP adds do not read first, and the stages are pinned with sched_barrier.  (Software-pipelining
-  // A(q+1) in front of B(q) saved a few pads but cost 13-18 VGPRs in the P = 8 variants and was
-  // no faster anywhere.)
-  struct Pre { unsigned ps[P + 1]; unsigned suf[P + 1]; };   // suf[k] = sum of the lane's last k columns
-
-  template <int W>
-  static __device__ __forceinline__ void stage_a(const unsigned (&C)[P][W], int q, Pre& r)
-  {
-    r.ps[0] = 0;
-    if constexpr (TR3) {                                   // no prefix sums: ps[k + 1] carries the triple sum T of column k as it is
-#pragma unroll
-      for (int k = 0; k < P; ++k) r.ps[k + 1] = C[k][q];
-      return;
-    }
-#pragma unroll
-    for (int k = 0; k < P; ++k) r.ps[k + 1] = r.ps[k] + C[k][q];
-#pragma unroll
-    for (int k = 1; k <= H && k <= P; ++k) r.suf[k] = r.ps[P] - r.ps[P - k];
-  }
-
-  // Unpacked: the window sum is the key (bias trick).  Packed: the window sums of disparities
-  // dbase+2q (low half) and dbase+2q+1 (high half) become two keys (SAD << 16) | d.
-  // MASK (packed h = 6, 7 only; every other variant removes missing candidates through the start
-  // values of the column sums, see run()): 0 = every candidate of the chunk exists for every pixel;
-  // 2 = candidate j of the wave exists for column p of lane l iff bit l of M[j - p + P-1] is set
-  // (d <= x-h near the left image edge).  plan_for() gives these variants exact plans only (no chunk
-  // runs past MaxDisparity); the extra candidate's empty high half is dropped here (qn = 1).
-  // JOFS = index of the array's first candidate within the wave (0; ND for the extra candidate).
-  // LOW_ONLY = the register holds one real candidate (the extra one, low half): no key for the high half.
-  template <int MASK, int JOFS, bool LOW_ONLY = false>
-  static __device__ __forceinline__ void stage_b(const Pre& r, int q, const Masks& M,
-                                                 unsigned (&best)[P], unsigned dbase, int qn)
-  {
-    // window sum of column p = own columns + last (h-p) columns of the left lane + first (p+h-P+1)
-    // columns of the right lane.  The DPP adds are issued as two sweeps over p (all "left" pulls,
-    // then all "right" pulls): a DPP instruction that reads a VGPR written by the instruction just
-    // before it costs wait states, so the two adds of one column are kept P instructions apart.
-    unsigned s[P];
-    if constexpr (TR3) {
-      // window of column p = T(p-h) + T(p-h+3) + ... ((2h+1)/3 terms); T(i) of this lane for 0 <= i < P, of the
-      // left lane for i < 0 (T(i+P) there), of the right lane for i >= P.  Own-lane terms first, then the
-      // left pulls, then (second sweep, as in the plain form) the right pulls: every pull is one DPP add.
-      constexpr int M3 = (2 * H + 1) / 3;
-      if constexpr (H == 4 && P == 4) {
-        // the four windows by hand: T0 + T3 serves two of them (once as itself, once pulled from the left
-        // lane as a whole: left(T0) + left(T3) = left(T0 + T3)) -- 7 instructions instead of 8
-        const unsigned t0 = r.ps[1], t1 = r.ps[2], t2 = r.ps[3], t3 = r.ps[4];
-        const unsigned u = t0 + t3;
-        s[1] = u + from_left(t1);
-        s[2] = t1 + from_left(t2);
-        s[3] = t2 + from_left(t3);
-        s[0] = t2 + from_left(u);                              // (three instructions after u: no DPP hazard pad)
-#pragma unroll
-        for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
-        s[2] += from_right(t0);
-        s[3] += from_right(t1);
-      } else {
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        bool have = false;
-#pragma unroll
-        for (int j = 0; j < M3; ++j) {
-          const int i = p - H + 3 * j;
-          if (i >= 0 && i < P) { s[p] = have ? s[p] + r.ps[i + 1] : r.ps[i + 1]; have = true; }
-        }
-#pragma unroll
-        for (int j = 0; j < M3; ++j) {
-          const int i = p - H + 3 * j;
-          if (i < 0) { s[p] = have ? s[p] + from_left(r.ps[i + P + 1]) : from_left(r.ps[i + P + 1]); have = true; }
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
-#pragma unroll
-      for (int p = 0; p < P; ++p)
-#pragma unroll
-        for (int j = 0; j < M3; ++j) {
-          const int i = p - H + 3 * j;
-          if (i >= P) s[p] += from_right(r.ps[i - P + 1]);
-        }
-      }
-    } else if constexpr (H <= P) {
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int a = p - H, b = p + H;
-        const int lo = a > 0 ? a : 0, hi = b < P - 1 ? b : P - 1;
-        s[p] = lo == 0 ? r.ps[hi + 1] : r.ps[hi + 1] - r.ps[lo];
-        if (a < 0) s[p] += from_left(r.suf[-a]);
-      }
-#pragma unroll
-      for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));      // v_add_u32_dpp twice, not v_mov_dpp x2 + v_add3
-#pragma unroll
-      for (int p = 0; p < P; ++p)
-        if (p + H > P - 1) s[p] += from_right(r.ps[p + H - P + 1]);
-    } else {
-      // P < h < 2P (BlockSize 19..31): the window covers the whole lane, up to the whole neighbour
-      // lane on each side, and H-p-P (left) / p+H-2P+1 (right) columns of the lane after that:
-      // the neighbours' totals once, the second hop as v_mov_dpp of the partial sum followed by a
-      // DPP add one lane further.
-      constexpr int N2 = H - P;                              // most columns needed from a lane two away
-      unsigned t2l[N2 + 1], t2r[N2 + 1];
-#pragma unroll
-      for (int k = 1; k <= N2; ++k) { t2l[k] = from_left(r.suf[k]); t2r[k] = from_right(r.ps[k]); }
-      if constexpr (2 * P - H - 1 <= 0) {
-        // h >= 2P-1 (P = 4, h = 7; P = 8, h = 15): every window holds BOTH neighbour lanes whole -- their
-        // totals join the lane's own once per candidate instead of once per column
-        unsigned u3 = r.ps[P] + from_left(r.ps[P]);
-        asm("" : "+v"(u3));
-        u3 += from_right(r.ps[P]);
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const int nl = H - p;
-          s[p] = nl > P ? u3 + from_left(t2l[nl - P]) : u3;
-        }
-#pragma unroll
-        for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const int nr = p + H - P + 1;
-          if (nr > P) s[p] += from_right(t2r[nr - P]);
-        }
-      } else {
-      const unsigned tl = from_left(r.ps[P]), tr = from_right(r.ps[P]);
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int nl = H - p;                                // columns left of the lane (>= H-P+1 > 0)
-        if (nl >= P) { s[p] = r.ps[P] + tl; if (nl > P) s[p] += from_left(t2l[nl - P]); }
-        else s[p] = r.ps[P] + from_left(r.suf[nl]);
-      }
-#pragma unroll
-      for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int nr = p + H - P + 1;                        // columns right of the lane (> 0)
-        if (nr >= P) { s[p] += tr; if (nr > P) s[p] += from_right(t2r[nr - P]); }
-        else s[p] += from_right(r.ps[nr]);
-      }
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      if constexpr (PK) {
-        unsigned ke = (s[p] << 16) | (dbase + 2 * q);             // v_lshl_or_b32
-        if constexpr (LOW_ONLY) {
-          if (MASK == 2) {
-            const int ie = JOFS + 2 * q - p + P - 1;
-            ke = sel_lanes(M.at(ie < NM ? ie : NM - 1), ke);
-          }
-          best[p] = ke < best[p] ? ke : best[p];
-          continue;
-        }
-        unsigned ko = __builtin_amdgcn_perm(s[p], dbase + 2 * q + 1, 0x07060100u);   // (s & 0xffff0000) | d: one v_perm_b32
-        if (MASK == 2) {
-          const int ie = JOFS + 2 * q - p + P - 1, io = ie + 1;
-          ke = sel_lanes(M.at(ie < NM ? ie : NM - 1), ke);
-          ko = (JOFS != 0 && 2 * q + 1 >= qn) ? KEY_INVALID : sel_lanes(M.at(io < NM ? io : NM - 1), ko);
-        }
-        const unsigned m = ke < ko ? ke : ko;
-        best[p] = m < best[p] ? m : best[p];                      // v_min3_u32
-      } else {
-        unsigned k = s[p];
-        if (MASK == 2) {
-          const int i = JOFS + q - p + P - 1;
-          k = sel_lanes(M.at(i < NM ? i : NM - 1), k);
-        }
-        best[p] = k < best[p] ? k : best[p];
-      }
-    }
-  }
-
-  // FL: window sums of one candidate as PURE sums of columns inside the window (no prefix
-  // differences: a valid window never mixes with a penalised column, so every partial sum of a valid
-  // window is an exactly representable integer + index fraction).  own part = prefix, suffix or whole
-  // lane; + suffix of the left lane and / or prefix of the right lane through one DPP add each.
-  template <int W>
-  static __device__ __forceinline__ void window_sums_fl(const unsigned (&C)[P][W], int q, float (&s)[P])
-  {
-    float ps[P + 1], sf[P];
-    ps[1] = __uint_as_float(C[0][q]);
-#pragma unroll
-    for (int k = 1; k < P; ++k) ps[k + 1] = ps[k] + __uint_as_float(C[k][q]);
-    sf[P - 1] = __uint_as_float(C[P - 1][q]);
-#pragma unroll
-    for (int k = P - 2; k >= 1; --k) sf[k] = sf[k + 1] + __uint_as_float(C[k][q]);
-    sf[0] = ps[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const float own = (p - H <= 0 && p + H >= P - 1) ? ps[P] : (p - H <= 0 ? ps[p + H + 1] : sf[p - H]);
-      s[p] = own;
-      if (p - H < 0) s[p] += __uint_as_float(from_left(__float_as_uint(sf[P + p - H])));
-    }
-#pragma unroll
-    for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-      if (p + H > P - 1) s[p] += __uint_as_float(from_right(__float_as_uint(ps[p + H - P + 1])));
-  }
-
-  template <int W>
-  static __device__ __forceinline__ void reduce_row_fl(const unsigned (&C)[P][W], unsigned (&best)[P])
-  {
-#pragma unroll
-    for (int q = 0; q + 2 <= W; q += 2) {
-      float sa[P], sb[P];
-      window_sums_fl(C, q, sa);
-      __builtin_amdgcn_sched_barrier(0);
-      window_sums_fl(C, q + 1, sb);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int p = 0; p < P; ++p)        // inline asm: fminf() makes hipcc canonicalise every operand first (a v_max_f32 x, x each)
-        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(best[p]) : "v"(sa[p]), "v"(sb[p]));
-    }
-    if constexpr (W % 2 != 0) {
-      float sa[P];
-      window_sums_fl(C, W - 1, sa);
-#pragma unroll
-      for (int p = 0; p < P; ++p) asm("v_min_f32 %0, %0, %1" : "+v"(best[p]) : "v"(sa[p]));
-    }
-  }
-
-  template <int MASK, int JOFS, int W>
-  static __device__ __forceinline__ void reduce_row(const unsigned (&C)[P][W], const Masks& M,
-                                                    unsigned (&best)[P], unsigned dbase, int qn)
-  {
-#pragma unroll
-    for (int q = 0; q < W; ++q) {
-      Pre cur;
-      stage_a(C, q, cur);
-      __builtin_amdgcn_sched_barrier(0);
-      stage_b<MASK, JOFS, PK && W == 1>(cur, q, M, best, dbase, qn);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
-  static __device__ void run(const CwArgs& a)
-  {
-    extern __shared__ __attribute__((aligned(16))) unsigned smem[];
-    const Job& j = a.j;
-    const int nt = blockDim.x;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dcl = wv * ND;                              // first disparity of this wave within the pass
-    const int dc = a.dbase + dcl;                         // ... and absolute
-    const int RW = TW + a.dpad + 1;                       // R values per ring row (16 bytes' worth aligned)
-    const int ROWW = TW + RW;                             // pixels per ring row: L[TW] then R[RW]
-    Px* ring = reinterpret_cast<Px*>(smem);               // (NR + 1) rows; row NR stays zero
-    unsigned* rowbest = smem + (size_t)(NR + 1) * ROWW * sizeof(Px) / 4;   // [NB][RBW]  (ROWW * sizeof(Px) is a multiple of 16)
-    unsigned char* lut = reinterpret_cast<unsigned char*>(rowbest + NB * RBW);  // [maxdisp+1]
-
-    // Grid = (strips x frames, tiles): workgroups are dispatched x-fastest, so ALL workgroups of the
-    // leftmost tile (the ones that mask keys in the packed h = 6, 7 variants and run longest) start in
-    // the first round instead of trailing the launch.
-    const int tile = blockIdx.y + a.tile0;
-    const int tx = a.tx0 + tile * STEP;                   // image column of lane 0, p 0
-    const int f = blockIdx.x / a.nstrips;
-    const int strip = blockIdx.x - f * a.nstrips;
-    const uint8_t* __restrict__ Lg = j.left + (size_t)f * j.left_frame_stride;
-    const uint8_t* __restrict__ Rg = j.right + (size_t)f * j.right_frame_stride;
-    uint8_t* __restrict__ Og = j.out + (size_t)f * j.out_frame_stride;
-
-    const int ys = j.y0 + strip * a.th;                   // strip rows [ys, ye)
-    const int ye = min(ys + a.th, j.y1);
-    // output columns of this tile (tile 0 also owns everything left of its interior)
-    const int ox0 = max(tile == 0 ? j.x0 : tx + OL, j.x0);
-    const int ox1 = min(tx + OL + STEP, j.x1);
-    if (ys >= ye || ox0 >= ox1) return;
-
-    // ---- one-time setup: zero row, row-best buffers, output LUT, first ring row ----------------
-    // Ring row of image row yy: L columns [tx, tx+TW) then R columns [tx-dbase-dpad, tx-dbase+TW), one u32 per
-    // pixel (shifted by ksh in the unpacked variant), zero outside the image.
-    for (int i = tid; i < ROWW; i += nt) ring[NR * ROWW + i] = 0;
-    for (int i = tid; i < NB * RBW; i += nt) rowbest[i] = KEY_INVALID;
-    for (int i = tid; i <= j.maxdisp; i += nt)
-      lut[i] = (unsigned char)(j.raw ? min(i, 255) : (i * 255) / j.maxdisp);     // sad.go:91-93
-    {
-      const int yy = ys - H;                              // step 0's entering row -> slot 0
-      for (int i = tid; i < ROWW; i += nt) {                // i = physical position in the ring row
-        const bool isR = i >= TW;
-        const int col = isR ? tx - a.dbase - a.dpad + logical(i - TW, RW) : tx + logical(i, TW);
-        unsigned v = 0u;
-        if (yy >= 0 && yy < j.h && col >= 0 && col < j.w)
-          v = (unsigned)(isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride)[col];
-        if constexpr (TR3) {                                 // + the two pixels to the right in bytes 1 and 2
-#pragma unroll
-          for (int k = 1; k < 3; ++k)
-            if (yy >= 0 && yy < j.h && col + k >= 0 && col + k < j.w)
-              v |= (unsigned)(isR ? Rg + (size_t)(yy - j.row0) * j.rstride : Lg + (size_t)(yy - j.row0) * j.lstride)[col + k] << (8 * k);
-        }
-        ring[i] = (Px)(FL ? __float_as_uint((float)v) : v << a.pixshift);
-      }
-    }
-    __syncthreads();
-
-    // ---- this wave's share of the row streaming and of the output -------------------------------
-    // L positions (= output pixels) [wv*shl, (wv+1)*shl), R positions [wv*shr, (wv+1)*shr) of a ring
-    // row (physical positions: see SWZ); lane l takes positions l, l+64, ...  lcol / rcol: image column
-    // of the pixel stored there, NOT_MINE otherwise.
-    // The packed variants fetch rows with raw buffer loads: resource = the row, vector offset = the
-    // column, range-checked by the hardware against the row width -- columns left or right of the
-    // image (and NOT_MINE, as unsigned) read as 0 without branches or address arithmetic.
-    constexpr int NOT_MINE = (int)0x80000000;
-    int il0, ir0;
-    int lcol[MAXL], rcol[MAXR];
-    // The unpacked variants run at their 128-register limit: held across the row loop, these
-    // loop-invariant per-lane values were spilled to scratch in the set-up code and reloaded in every
-    // step (14-21 VGPRs, 60-88 bytes of scratch per lane in round 1).  There (RECOMPUTE_SHARE) the
-    // columns are re-derived in every step from a lane id the compiler cannot see through (one add
-    // each) and "this position is mine" is a wave-uniform 64-bit lane mask per position, held in SGPRs
-    // and applied as the branch condition itself (s_and_saveexec, no vector instruction).
-    constexpr bool RECOMPUTE_SHARE = !PK && !FL && !X_NORECOMP;
-    unsigned long long mineL[MAXL], mineR[MAXR];
-    auto row_share = [&](int ln) {                        // ln = lane
-      il0 = wv * a.shl + ln; ir0 = wv * a.shr + ln;
-#pragma unroll
-      for (int v = 0; v < MAXL; ++v) {
-        const int i = il0 + 64 * v;
-        const int col = tx + logical(i, TW);
-        lcol[v] = (RECOMPUTE_SHARE || (ln + 64 * v < a.shl && i < TW)) ? col : NOT_MINE;
-      }
-#pragma unroll
-      for (int v = 0; v < MAXR; ++v) {
-        const int i = ir0 + 64 * v;
-        const int col = tx - a.dbase - a.dpad + logical(i, RW);
-        rcol[v] = (RECOMPUTE_SHARE || (ln + 64 * v < a.shr && i < RW)) ? col : NOT_MINE;
-      }
-    };
-    row_share(lane);
-#pragma unroll
-    for (int v = 0; v < MAXL; ++v) mineL[v] = __builtin_amdgcn_ballot_w64(lane + 64 * v < a.shl && il0 + 64 * v < TW);
-#pragma unroll
-    for (int v = 0; v < MAXR; ++v) mineR[v] = __builtin_amdgcn_ballot_w64(lane + 64 * v < a.shr && ir0 + 64 * v < RW);
-    // TR3: a pixel triple is one unaligned dword load; a wave that streams a position left of column 0 takes the
-    // slower path of load_row / land_row for all its positions (wave-uniform choice, fixed for the workgroup's life)
-    bool whole_words = false;
-    if constexpr (TR3) {
-      bool ok = true;
-#pragma unroll
-      for (int v = 0; v < MAXL; ++v) ok = ok && (lcol[v] == NOT_MINE || lcol[v] >= 0);      // (<= w-5: see load_row)
-#pragma unroll
-      for (int v = 0; v < MAXR; ++v) ok = ok && (rcol[v] == NOT_MINE || rcol[v] >= 0);
-      whole_words = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-    }
-    auto mine_l = [&](int v) -> bool { if constexpr (RECOMPUTE_SHARE) return __builtin_amdgcn_inverse_ballot_w64(mineL[v]); else return lcol[v] != NOT_MINE; };
-    auto mine_r = [&](int v) -> bool { if constexpr (RECOMPUTE_SHARE) return __builtin_amdgcn_inverse_ballot_w64(mineR[v]); else return rcol[v] != NOT_MINE; };
-    unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
-    auto load_row = [&](int yy) {
-      if (yy >= 0 && yy < j.h) {
-        const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * j.lstride;
-        const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * j.rstride;
-        if constexpr (PK || FL || X_BUFLOAD) {
-          // one resource per row (scalar arithmetic): base = the row, num_records = its width
-          const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lrow), 0, j.w, 0x00020000);
-          const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(rrow), 0, j.w, 0x00020000);
-          if constexpr (TR3) {
-            // one (unaligned) dword per pixel triple.  Workgroups in this form never reach the row's right end:
-            // their last lane column is <= w-3 (k_colwave) and == w-1 (mod 4) like every tile's (tile origins
-            // == w mod 4), i.e. <= w-5, so the dword of every used position ends at column w-2 or before (the R
-            // part's spare last position may lie further right: it is never an operand).
-            // At the left end a dword that starts at column -1 or -2 is partly outside and would
-            // read as 0 whole, while it holds the pixels 0, 1: a wave that streams such positions loads the
-            // dword of column 0 for them and shifts when it lands it (columns <= -3: all outside, 0 is right).
-#pragma unroll
-            for (int v = 0; v < MAXL; ++v)
-              pfl[v] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsL, whole_words ? lcol[v] : max(lcol[v], min(lcol[v] + 2, 0)), 0, 0);
-#pragma unroll
-            for (int v = 0; v < MAXR; ++v)
-              pfr[v] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsR, whole_words ? rcol[v] : max(rcol[v], min(rcol[v] + 2, 0)), 0, 0);
-          } else {
-#pragma unroll
-            for (int v = 0; v < MAXL; ++v) pfl[v] = __builtin_amdgcn_raw_buffer_load_b8(rsL, lcol[v], 0, 0);
-#pragma unroll
-            for (int v = 0; v < MAXR; ++v) pfr[v] = __builtin_amdgcn_raw_buffer_load_b8(rsR, rcol[v], 0, 0);
-          }
-        } else {
-          // the unpacked variants run at their register limit; there the plain loads allocate better
-          // (B16 D64: 35.4 us against 39.9 with buffer loads)
-#pragma unroll
-          for (int v = 0; v < MAXL; ++v) pfl[v] = (unsigned)lcol[v] < (unsigned)j.w ? (unsigned)lrow[(unsigned)lcol[v]] : 0u;
-#pragma unroll
-          for (int v = 0; v < MAXR; ++v) pfr[v] = (unsigned)rcol[v] < (unsigned)j.w ? (unsigned)rrow[(unsigned)rcol[v]] : 0u;
-        }
-      } else {
-#pragma unroll
-        for (int v = 0; v < MAXL; ++v) pfl[v] = 0u;
-#pragma unroll
-        for (int v = 0; v < MAXR; ++v) pfr[v] = 0u;
-      }
-    };
-    auto land_row = [&](Px* dst) {
-      if constexpr (TR3) {
-        // the triple of column c from the dword loaded at column ld >= c: moved up by ld - c (0..2) bytes
-        auto place = [&](unsigned dw, int col) -> unsigned {
-          if (whole_words) return dw & 0xffffffu;
-          const int up = max(col, min(col + 2, 0)) - col;
-          return (dw << (8 * up)) & 0xffffffu;
-        };
-#pragma unroll
-        for (int v = 0; v < MAXL; ++v)
-          if (mine_l(v)) dst[il0 + 64 * v] = (Px)place(pfl[v], lcol[v]);
-#pragma unroll
-        for (int v = 0; v < MAXR; ++v)
-          if (mine_r(v)) dst[TW + ir0 + 64 * v] = (Px)place(pfr[v], rcol[v]);
-        return;
-      }
-#pragma unroll
-      for (int v = 0; v < MAXL; ++v)
-        if (mine_l(v)) dst[il0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfl[v]) : PK ? pfl[v] : pfl[v] << a.pixshift);
-#pragma unroll
-      for (int v = 0; v < MAXR; ++v)
-        if (mine_r(v)) dst[TW + ir0 + 64 * v] = (Px)(FL ? __float_as_uint((float)pfr[v]) : PK ? pfr[v] : pfr[v] << a.pixshift);
-    };
-    const unsigned kmask = (1u << a.ksh) - 1u;
-    auto finalize = [&](int t) {                          // output row of step t, this wave's pixels
-      const int y = ys + t - 2 * H;
-      unsigned* rb = rowbest + (t & 1) * RBW;
-      uint8_t* orow = Og + (size_t)(y - j.oy) * j.ostride;  // uniform base + 32-bit lane offset
-      const size_t krow = ((size_t)f * (j.y1 - j.y0) + (y - j.y0)) * a.kw;
-#pragma unroll
-      for (int v = 0; v < MAXL; ++v) {
-        if (mine_l(v)) {
-          const int x = lcol[v], i = x - tx;                // i = column within the tile (>= 0)
-          const int ri = (i & (P - 1)) * RBP + (i >> (P == 8 ? 3 : 2));
-          unsigned k = rb[ri];
-          rb[ri] = KEY_INVALID;
-          if (x >= ox0 && x < ox1) {
-            if (a.kin) k = min(k, a.kin[krow + (unsigned)(x - j.x0)]);
-            if (a.kout) {
-              a.kout[krow + (unsigned)(x - j.x0)] = k;
-            } else {
-              // x <= h: d = 0 is the only candidate (sad.go:66-69)
-              unsigned dk = k & kmask;
-              if constexpr (FL) {                           // key = window SAD (integer) + local candidate index / 256
-                const float kf = __uint_as_float(k);
-                dk = (unsigned)a.dbase + (unsigned)((kf - __builtin_floorf(kf)) * 256.0f + 0.5f);
-              }
-              const unsigned d = x <= H ? 0u : min(dk, (unsigned)j.maxdisp);
-              orow[(unsigned)(x - j.ox)] = lut[d];
-            }
-          }
-        }
-      }
-    };
-
-    // ---- per-lane state ------------------------------------------------------------------------
-    const int x0 = tx + P * lane;                         // first column of this lane
-    const bool lane_valid = x0 < j.w;                     // (w - tx) % P == 0: all-or-nothing
-    const bool xtra = wv == a.xw;                         // this wave also owns candidate dx = nw*ND
-    const int dx = a.dbase + a.nw * ND;
-    // Candidates d > x-h do not exist near the left image edge (sad.go:66-69).  Instead of masking
-    // their keys in every row (which made the leftmost tile's workgroups the critical path of the
-    // whole launch), their column sums start with a penalty that outlives the sliding updates:
-    // a pixel's candidate d is missing exactly when its window's first column c0 = x-h is < d.
-    //   unpacked: every column c < d starts at 2^27 (17 columns * 2^27 + any key < 2^32);
-    //   packed:   u16 sums cannot hold more than one penalty per window, so only columns
-    //             c < d with c == d-1 (mod 2h+1) start at PEN = (2h+1)^2*255: every full window
-    //             holds exactly one column of that class, and it is < d iff c0 < d; a penalised sum
-    //             is >= the worst d = 0 sum and <= 2*PEN, which fits 16 bits for h <= 5.
-    // Windows clipped on the left (x <= h) only have d = 0 and are forced to lut[0] at the output;
-    // packed windows clipped on the right can meet missing candidates only when w <= D + 2h + 2:
-    // plan_job() gives those frames the unpacked variant.  Packed h = 6, 7 (NEED_MASK) masks
-    // keys instead: candidate j of the wave is valid for column p of lane l iff
-    // tx + P*l + p - h >= dc + j, i.e. l >= ceil((dc + h - tx + (j - p)) / P): one 64-bit lane mask
-    // per value of j - p, kept in SGPRs and applied with one v_cndmask_b32 per key.
-    constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
-    constexpr bool use_pen = !NEED_MASK;
-    // Lane masks (Masks above): NMB distinct 64-bit masks in SGPR pairs + the carry bits, held across the
-    // row loop; the mask of a key is a scalar select at its use.  (Measured alternatives, DESIGN.md
-    // section 6b: all ND + P masks ready-made cost 32-40 SGPRs, 13-25 of them parked in VGPR lanes; a
-    // vector compare per key instead of a mask costs 8 % on config 5.)
-    Masks M;
-    {
-      const int T0 = dc + H - tx;                         // mask k: lanes >= max(0, floor((T0 + k) / P))
-      const int q0 = T0 >= 0 ? T0 / P : -((-T0 + P - 1) / P);
-      const int c = T0 - q0 * P;                          // 0 .. P-1
-#pragma unroll
-      for (int i = 0; i < NMB; ++i) {
-        const int l0 = q0 + i > 0 ? q0 + i : 0;
-        M.mb[i] = (NEED_MASK && l0 < 64) ? (~0ull << l0) : 0ull;
-      }
-      M.carry = 0u;
-#pragma unroll
-      for (int r = 0; r < P; ++r) M.carry |= (r + c >= P) ? (1u << r) : 0u;
-      M.carry = (unsigned)__builtin_amdgcn_readfirstlane((int)M.carry);
-    }
-    // Candidates d > D (a chunk that runs past MaxDisparity) exist for no pixel: same trick with the
-    // class c == w-1 (mod 2h+1), 0 <= c < w, which every window has exactly once -- also the windows
-    // clipped at the right image edge (they end in column w-1).  Columns >= w must start at 0: they
-    // never accumulate and their neighbours' windows sum over them.
-    auto init_sum = [&](int col, int d) -> unsigned {     // start value of the column sum of (col, d)
-      const bool in = col >= 0 && col < j.w;
-      if constexpr (PK) {
-        if (!use_pen || !in) return 0u;
-        // TR3: the register of column c sums the columns c, c+1, c+2, and a window is the registers of
-        // c0, c0+3, ... (c0 = x-h): the penalised class is three consecutive columns of every 2h+1, so that
-        // again exactly one register of a window is in it (the residues of c0, c0+3, ... mod 2h+1 fall into
-        // the (2h+1)/3 different thirds) -- and it is < d whenever c0 is.
-        constexpr int CW = TR3 ? 3 : 1;
-        if (d > j.maxdisp) return (j.w - 1 - col) % B1 < CW ? PEN : 0u;
-        return (col < d && (d - 1 - col) % B1 < CW) ? PEN : 0u;
-      } else if constexpr (FL) {
-        // f32 sums: the biased column class carries (candidate index within the pass) / 256 -- the sums
-        // stay exact while (2h+1)^2 * 255 * 256 < 2^24 (h <= 7) -- and a penalised column 2^16, above
-        // every valid window sum; a penalised sum need not be exact, it only has to lose
-        const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
-        return __float_as_uint((biased ? (float)(d - a.dbase) * (1.0f / 256.0f) : 0.0f) + ((in && (col < d || d > j.maxdisp)) ? 65536.0f : 0.0f));
-      } else {
-        const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
-        return (biased ? (unsigned)d : 0u) + ((in && (col < d || d > j.maxdisp)) ? PEN : 0u);
-      }
-    };
-    unsigned C[P][NC], CX[P][1];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int col = x0 + p;
-#pragma unroll
-      for (int q = 0; q < NC; ++q) {
-        if constexpr (PK) C[p][q] = init_sum(col, dc + 2 * q) | (init_sum(col, dc + 2 * q + 1) << 16);
-        else C[p][q] = init_sum(col, dc + q);
-      }
-      // the extra register's high half is candidate dx+1 > D: never updated, starts penalised
-      if constexpr (PK) CX[p][0] = init_sum(col, dx) | (init_sum(col, dx + 1) << 16);
-      else CX[p][0] = init_sum(col, dx);
-    }
-    // packed h = 6, 7: does this wave have to mask keys?  (wave-uniform)
-    const int qn = min(ND, j.maxdisp - dc + 1);           // chunk runs past MaxDisparity: first qn only
-    // some pixel of this tile has d <= x-h < chunk end (exact plans: qn == ND)
-    const bool key_mask = !use_pen && max(ox0, 0) - H < min(dc + ND - 1 + (xtra ? 1 : 0), j.maxdisp);
-
-    // this lane's operands inside a ring row (pixel index): L at lofs, R value m at rofs + m
-    // (SWZ: logical quad 2*lane + c + j of a part lives at quad lane + (c + j) / 2 of half (c + j) & 1;
-    //  c = (dpad - dcl - (ND-1)) / 4 = 2 * (nw - wv) is even, so even j read half 0 and odd j half 1)
-    const int lofs = SWZ ? 4 * lane : P * lane;
-    const int rofs = TW + (SWZ ? 4 * (a.nw - wv + lane) : (a.dpad - dcl - (ND - 1)) + P * lane);   // 16-byte aligned by construction (dpad = nw*ND + XOFF)
-    const int rxofs = TW + (SWZ ? 4 * lane : (a.dpad - a.nw * ND - XOFF) + P * lane);             // extra candidate: R value of column p at +XOFF+p
-    const int lhalf = SWZ ? TW / 2 : 0, rhalf = SWZ ? RW / 2 : 0;
-
-    // ---- main loop: step t brings in image row ys-H+t (ring slot t % NR) ------------------------
-    //   load    this wave's share of row t+1 (global -> registers; lands after the arithmetic)
-    //   update  column sums: + row t, - row t-(2h+1)
-    //   reduce  window sums -> per-pixel minimum of this wave's candidates -> ds_min into row buffer t&1
-    //   land    row t+1 in the slot of the row that left the window one step ago
-    //   output  this wave's pixels of row buffer (t-1)&1 (complete since the last barrier)
-    //   barrier
-    const int nsteps = (ye - ys) + 2 * H;
-    int slot_in = 0;
-#ifdef SADHIP_STAMPS
-    unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_prev = 0;
-#define SADHIP_STAMP(K) do { if (a.stamps) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-                             st_sum[K] += now_ - st_prev; st_prev = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define SADHIP_STAMP0() do { if (a.stamps) st_prev = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SADHIP_STAMP(K) do {} while (0)
-#define SADHIP_STAMP0() do {} while (0)
-#endif
-    asm volatile("; SADHIP_ROWLOOP form=%c0 (tools/valu_budget.py: 3 = triple-column, 1 = plain)" :: "n"(TR3 ? 3 : 1));
-    for (int t = 0; t < nsteps; ++t) {
-      if constexpr (RECOMPUTE_SHARE) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        row_share(ln);
-      }
-      SADHIP_STAMP0();
-      // (also in the last step: one harmless row more keeps loads and landings unconditional)
-      load_row(ys - H + t + 1);
-      const int so = slot_in + 2;                         // row t-(2h+1): NR - (2h+1) = 2 slots ahead
-      const int slot_out = t > 2 * H ? (so >= NR ? so - NR : so) : NR;   // window not full yet: zero row
-      const int sn = slot_in + 1 == NR ? 0 : slot_in + 1;
-      const Px* rin = ring + slot_in * ROWW;
-      const Px* rout = ring + slot_out * ROWW;
-      unsigned best[P];
-#pragma unroll
-      for (int p = 0; p < P; ++p) best[p] = FL ? 0x7f800000u : KEY_INVALID;     // FL: +inf (keys are non-negative floats)
-      const bool out_row = t >= 2 * H;
-      if (lane_valid) update_columns(C, Src{rin + lofs, rin + lofs + lhalf}, Src{rin + rofs, rin + rofs + rhalf},
-                                     Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rofs, rout + rofs + rhalf});
-      SADHIP_STAMP(0);
-      if (out_row) {
-        if constexpr (FL) reduce_row_fl(C, best);
-        else if (NEED_MASK && key_mask) {                 // leftmost tiles only
-          asm volatile("; SADHIP_MASKED_BEGIN (tools/valu_budget.py: not on the common path)");
-          reduce_row<2, 0>(C, M, best, (unsigned)dc, qn);
-          asm volatile("; SADHIP_MASKED_END");
-        }
-        else reduce_row<0, 0>(C, M, best, (unsigned)dc, qn);
-      }
-      if (xtra) {                                         // the odd candidate dx (wave-uniform branch)
-        asm volatile("; SADHIP_XTRA_BEGIN (tools/valu_budget.py counts this path separately)");
-        __builtin_amdgcn_sched_barrier(0);
-        if (lane_valid)
-          extra_update(CX, Src{rin + lofs, rin + lofs + lhalf}, Src{rin + rxofs, rin + rxofs + rhalf},
-                       Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rxofs, rout + rxofs + rhalf});
-        if (out_row) {
-          if constexpr (FL) reduce_row_fl(CX, best);
-          else if constexpr (NEED_MASK) reduce_row<2, ND>(CX, M, best, (unsigned)dx, 1);   // also drops the empty high half
-          else reduce_row<0, 0>(CX, M, best, (unsigned)dx, 1);
-        }
-        asm volatile("; SADHIP_XTRA_END");
-      }
-      if (out_row) {
-        unsigned* rb = rowbest + (t & 1) * RBW + lane;
-#pragma unroll
-        for (int p = 0; p < P; ++p) atomicMin(rb + p * RBP, best[p]); // ds_min_u32
-      }
-      // One unconditional wait for the row loads (issued a whole update + reduce ago).  Left to
-      // itself hipcc waits inside each lane-masked store block of land_row and, unable to prove that
-      // one of them always runs, again at the loop head -- where vmcnt(0) also waits for the output
-      // bytes stored at the end of the previous step (a memory round trip per row and wave).
-      SADHIP_STAMP(1);
-      __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0); expcnt / lgkmcnt untouched
-      land_row(ring + sn * ROWW);
-      SADHIP_STAMP(2);
-      if (t - 1 >= 2 * H) finalize(t - 1);
-      SADHIP_STAMP(3);
-      wg_barrier();
-      SADHIP_STAMP(4);
-      slot_in = sn;
-    }
-    finalize(nsteps - 1);
-#ifdef SADHIP_STAMPS
-    if (a.stamps && lane == 0) {
-      unsigned long long* o = a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wv) * 8;
-      for (int k = 0; k < 5; ++k) o[k] = st_sum[k];
-      o[5] = (unsigned long long)nsteps;
-      o[6] = xtra ? 1 : 0;
-      o[7] = (unsigned long long)tile;
-    }
-#endif
-  }
-};
-
-
-// WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
-// TR: the kernel holds both forms of the row loop (Cw::TR3): the triple-column form for the workgroups whose tile does
-// not hold the image's last two columns, the plain form for the others.
-template <int P, int ND, int H, bool PK, int WB, bool W16, bool FL = false, bool TR = false>
-__global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
-{
-  if constexpr (TR) {                                         // per workgroup: the tile with the image's last two columns runs the plain form
-    using K = Cw<P, ND, H, PK, W16, FL, true>;
-    const int tx = a.tx0 + ((int)blockIdx.y + a.tile0) * K::STEP;
-    if (tx + K::TW + 2 <= a.j.w) K::run(a); else Cw<P, ND, H, PK, W16, FL, false>::run(a);
-  } else {
-    Cw<P, ND, H, PK, W16, FL, false>::run(a);
-  }
-}
-
 #ifdef SADHIP_NO_TR3
 constexpr bool kTripleColumns = false;
 #else
 constexpr bool kTripleColumns = true;
 #endif
-
-struct Plan { int p, nd, nw; bool pk, extra, w16; bool fl = false; };
-
-// LDS bytes of one workgroup of a plan (the layout at the top of Cw::run): 2h+3 ring rows and the
-// row of zeros, two row-best buffers, the output LUT.
-inline size_t plan_lds_bytes(const Plan& pl, int h, int maxdisp)
-{
-  const bool swz = pl.p == 8 && !pl.w16 && pl.nd == 8;
-  const size_t tw = 64 * (size_t)pl.p, rw = tw + (size_t)pl.nw * pl.nd + ((pl.w16 || swz) ? 7 : 3) + 1, roww = tw + rw;
-  return (size_t)(2 * h + 4) * roww * (pl.w16 ? 2 : 4) + (size_t)2 * 72 * pl.p * 4 + (size_t)((maxdisp + 1 + 15) & ~15);
-}
-struct Pass { Plan pl; int dbase; };              // candidates [dbase, dbase + nw*nd (+1)) of the job
-struct PassIo { int dbase; const unsigned* kin; unsigned* kout; int kw; };
-// launch geometry of one pass, as launch_t would launch it on the current device (sadhip_plan_describe_batch)
-struct PassGeom { int tiles = 0, strips = 0, rows = 0, per_cu = 0; bool device = false; };
-
-// Tuning aids.  The product build (libsadhip.so) reads NO environment variable: env_int() is the
-// constant default there, so a stray variable in the host process cannot change a plan.  The
-// diagnostics build (-DSADHIP_TUNING -> lib/libsadhip_tune.so, loaded by tools/ only) reads
-// SADHIP_TUNE_* once per process (a launch consults them a few hundred times while planning).
-#ifdef SADHIP_TUNING
-int env_int(const char* name, int dflt)
-{
-  struct Entry { const char* name; int value; bool set; };
-  static const auto table = [] {
-    static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
-                                        "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
-                                        "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
-                                        "SADHIP_TUNE_FCOL", "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE"};
-    std::vector<Entry> t;
-    for (const char* n : names) {
-      const char* e = getenv(n);
-      t.push_back(Entry{n, e ? atoi(e) : 0, e != nullptr});
-    }
-    return t;
-  }();
-  for (const Entry& e : table)
-    if (e.name == name || strcmp(e.name, name) == 0) return e.set ? e.value : dflt;
-  const char* e = getenv(name);                                 // not in the table: read it live
-  return e ? atoi(e) : dflt;
-}
-#else
-constexpr int env_int(const char*, int dflt) { return dflt; }
-#endif
-
-// Kernel variant for `count` consecutive candidates: columns per lane P, packed or not, chunk size
-// ND, wave count NW and whether the last wave carries one extra candidate (NW*ND + 1 == count, the
-// usual case: the UI's D is a multiple of 16).  Cost model: a workgroup advances at the pace of
-// its most loaded SIMD, i.e. ceil(NW/4) waves of (per-candidate work * ND + per-wave overhead) per
-// row.  exact: no chunk may run past the last candidate (packed h = 6, 7 masks keys with lane masks
-// that cannot express it).
-//   packed   (h <= 7): P = 4, ND in {4, 8, 12, 16} (h <= 4 also 20, 24; h = 5..7 with two-lane halos);
-//                      P = 8 (h = 5..7, when P = 4 has no plan: exact plans of the lane-mask variants), ND in {4, 8, 12}
-//   unpacked (h = 8; h = 6, 7 without an exact packed plan; SADHIP_TUNE_PK=0): P = 8, ND in {4, 8, 12}
-// Measured on MI355X: for h = 5..7 the P = 4 kernels -- 4..8 waves per workgroup, two to four
-// independent workgroups per CU -- beat the P = 8 ones (8..16 waves, one or two per CU) by 2-15 % although
-// their windows span five lanes instead of three (7.0 against 6.6 instructions per 64 candidates).
-static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int p);
-
-Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
-{
-  const int force_p = env_int("SADHIP_TUNE_P", 0);              // tuning aid: force the columns per lane
-  if (pk && h <= 7 && force_p != 8) {
-    const Plan pl = plan_count_p(h, pk, count, exact, maxdisp, 4);
-    if (pl.nw || force_p == 4 || h <= 4) return pl;
-  }
-  return plan_count_p(h, pk, count, exact, maxdisp, 8);
-}
-
-static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int p)
-{
-  Plan best{0, 0, 0, false, false, false};
-  const int force_nd = env_int("SADHIP_TUNE_ND", 0);            // tuning aids: force a chunk size / wave count
-  const int force_nw = env_int("SADHIP_TUNE_NW", 0);
-  long best_cost = 1L << 60;
-  // chunk sizes: P = 4 up to 24; P = 8 up to 12 for the penalty variants (packed h = 5), 8 otherwise --
-  // measured: the lane-mask variants spill at ND 12 (B15 D48: 47 vs 36 us) and the unpacked ones
-  // lose their u16 ring (B16 D48: 41 vs 37 us)
-  const int nd_max = p == 4 ? 24 : ((pk && h <= 5) ? 12 : 8);
-  for (int nd = 4; nd <= nd_max; nd += 4) {
-    if (force_nd && force_nd != nd) continue;
-    for (int nw = 4; nw <= 16; ++nw) {                          // (two-wave workgroups for D <= 48 measured 25-35 % slower)
-      if (force_nw && force_nw != nw) continue;
-      if (p == 4 && nw > 8) continue;                           // measured: 11-16 waves (one workgroup per CU) lose ~10 % to passes of 8 waves
-      if (p == 4 && h > 4 && nd > 16) continue;                 // two-lane halo kernels exist for ND 4, 8, 12, 16
-      if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
-      // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated
-      // for packed h = 7 and unpacked h = 8, chunk size 8, <= 8 waves; unpacked pixels << bitlen(D) must fit)
-      const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
-                       ((pk && h == 7) || (!pk && h >= 8 && maxdisp <= 255));
-      // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
-      const size_t lds_plan = plan_lds_bytes(Plan{p, nd, nw, pk, false, w16}, h, maxdisp);
-      if (lds_plan > (size_t)160 * 1024) continue;
-      const int slots = nw * nd;
-      if (slots + 1 < count) continue;
-      const bool extra = slots + 1 == count;
-      if (exact && !extra && slots != count) continue;
-      if (!extra && slots - nd >= count && nw > 4) continue;    // a whole wave would be idle
-      const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
-      // waves a CU can hold of this plan (LDS; 128 VGPRs = 16 waves for the unpacked kernels): with one
-      // 4-wave workgroup per CU nothing hides its latencies (measured: BlockSize 16, D 16 as 4 waves x 4
-      // candidates on a u32 ring, one workgroup per CU, 26.7 us; as 4 x 8 on the u16 ring, three per CU, 20.5)
-      const long resident = std::min<long>((long)((size_t)160 * 1024 / lds_plan) * nw, pk ? 20 : 16);
-      const long pct = resident <= 4 ? 200 : resident <= 8 ? 118 : 100;
-      const long cost = (long)((nw + 3) / 4) * per_wave * 64 * pct / 100 + nw;    // ties: fewer waves
-      if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra, w16}; }
-    }
-  }
-  return best;
-}
-
-// The whole disparity range [0, D] as one pass, or -- when D+1 candidates do not fit the waves a
-// workgroup may have -- as several full passes of `chunk` candidates plus a last pass for the rest
-// (see CwArgs).
-// Packed first; unpacked when the window SAD does not fit 16 bits (h = 8), when forced, or when a
-// packed h = 6, 7 kernel has no exact plan.  Empty result: the generic kernel runs the job.
-// narrow: the frame is at most D + 2h + 2 wide -- a right-clipped window of a packed variant could
-// meet a missing candidate without its penalty column, so only the unpacked variants (every column
-// penalised) may run.
-std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow);
-
-// plan_job with a one-entry memo per thread: a caller streams frames with the same parameters.
-std::vector<Pass> plan_job(int h, int maxdisp, bool narrow)
-{
-  thread_local int memo_h = -1, memo_d = -1, memo_n = -1;
-  thread_local std::vector<Pass> memo;
-  if (h != memo_h || maxdisp != memo_d || (int)narrow != memo_n) {
-    memo = plan_job_uncached(h, maxdisp, narrow); memo_h = h; memo_d = maxdisp; memo_n = narrow;
-  }
-  return memo;
-}
-
-#ifndef SADHIP_FCOL_DEFAULT
-#define SADHIP_FCOL_DEFAULT 0
-#endif
-
-std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
-{
-  std::vector<Pass> passes;
-  if (h < 1 || h > 15 || maxdisp < 1) return passes;
-  // the fast-run float variant: one pass of 4..8 waves x 8 candidates (+ the 8k+1-th on the last wave)
-  if (env_int("SADHIP_TUNE_FCOL", SADHIP_FCOL_DEFAULT) != 0 && h >= 4 && h <= 7 && maxdisp + 1 <= 65) {
-    const int count = maxdisp + 1;
-    int nw = (count - 1 + 7) / 8;                               // nw*8 + 1 >= count
-    if (nw < 4) nw = 4;
-    Plan pl{8, 8, nw, false, nw * 8 + 1 == count, false};
-    pl.fl = true;
-    passes.push_back(Pass{pl, 0});
-    return passes;
-  }
-  for (int variant = (h <= 7 && !narrow && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; variant < 2; ++variant) {
-    const bool pk = variant == 0;
-    if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
-    // unpacked keys ((2h+1)^2*255 << bitlen(D)) must stay below the 2^27 penalty
-    const int b1 = 2 * h + 1, ksh = 32 - __builtin_clz((unsigned)maxdisp);
-    if (!pk && ((long long)b1 * b1 * 255 << ksh) >= (1LL << 27)) break;
-    const bool exact = pk && h > 5;
-    // full passes: 8 waves of ND 16 (P 4) / 16 waves of ND 8 (P 8); two-lane halos: 8 waves of ND 8
-    const int chunk = env_int("SADHIP_TUNE_CHUNK", h <= 8 ? 128 : 64);
-    passes.clear();
-    int base = 0, rem = maxdisp + 1;
-    while (rem > 0) {
-      Plan pl = plan_count(h, pk, rem, exact, maxdisp);
-      if (pl.nw) { passes.push_back(Pass{pl, base}); rem = 0; break; }
-      if (rem <= chunk) break;                                  // no plan for the rest
-      pl = plan_count(h, pk, chunk, true, maxdisp);
-      if (!pl.nw) break;
-      passes.push_back(Pass{pl, base});
-      base += chunk; rem -= chunk;
-    }
-    if (rem == 0) return passes;
-  }
-  passes.clear();
-  return passes;
-}
-
-// ---- strip count of a launch ---------------------------------------------------------------------
-// base = workgroups per strip layer (tiles x frames), rows = output rows, h2 = 2h warm-up rows per strip,
-// cus = compute units, per_cu = workgroups of this kernel a CU holds.  Cost of ns strips of th rows:
-//   work per workgroup  = th + h2 + 4 rows (4: set-up, ring fill, first barrier)
-//   k = ceil(base*ns / cus) workgroups on the busiest CU (round-robin dispatch)
-//   k <= per_cu: one round; a workgroup with fewer neighbours runs faster -- measured single 1080p pairs:
-//                1 / 2 / 5 resident workgroups take 0.42 / 0.55 / 1.0 of the full-occupancy time per row
-//                -> duration factor 0.27 + 0.73 * k / per_cu
-//   k >  per_cu: between base*ns / (cus*per_cu) rounds (perfect balance) and ceil(k / per_cu) (the busiest CU): their mean
-//   + 0.15 of a workgroup's duration for the tail in both cases: workgroups are not equally long (the
-//   leftmost tiles mask keys, CUs differ), and the longer they are the longer the chip waits for the last
-//   one (measured: 128 1080p pairs as 1 / 4 strips 27.7 / 24.2 us per pair; config 5 with 16 pairs as
-//   1 / 2 / 4 / 6 rounds 228 / 218 / 213 / 210)
-static long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_rows)
-{
-  const long max_strips = std::max<long>(1, (rows + min_rows - 1) / min_rows);
-  const double slots = (double)cus * per_cu;
-  double best = 1e300;
-  long best_ns = 1;
-  for (long ns = 1; ns <= max_strips; ++ns) {
-    const long th = (rows + ns - 1) / ns;
-    if ((rows + th - 1) / th != ns) continue;                   // this strip height gives fewer strips: counted there
-    const long w = base * ns, k = (w + cus - 1) / cus;
-    const double whole = (double)((k + per_cu - 1) / per_cu);   // rounds on the busiest CU
-    const double t = (k <= per_cu ? 0.27 + 0.73 * (double)k / per_cu : 0.5 * ((double)w / slots + whole)) + 0.15;
-    const double cost = t * (double)(th + h2 + 4);
-    if (cost < best * 0.999) { best = cost; best_ns = ns; }     // ties: fewer strips
-  }
-  return best_ns;
-}
-
-static int cu_count()
-{
-  thread_local int dev_cached = -1, cus = 256;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return cus;
-  if (dev != dev_cached) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    dev_cached = dev;
-  }
-  return cus;
-}
 
 // workgroups of `kernel` a CU holds (registers, LDS, waves), asked from the runtime once per instantiation, shape and
 // thread; *asked (optional) = the runtime answered (false: no usable device, one workgroup per CU assumed)
@@ -1392,12 +44,10 @@ static int wgs_per_cu(Kernel kernel, int threads, size_t lds, bool* asked = null
 // part: 0 = every tile of the job; 1 = only the tiles before the first one that holds the image's last two
 // columns (the triple-column form, TR); 2 = only the tiles from that one on (the plain form next to it).
 // geom (optional): fill in the launch geometry and return without launching.
-template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false, bool FL = false, bool TR = false>
+template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false, bool TR = false>
 hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, int part = 0, PassGeom* geom = nullptr)
 {
-  using K = Cw<P, ND, H, PK, W16, FL, TR>;
-  static_assert(!TR || !FL, "");
-  if (FL && (io.kin || io.kout)) return hipErrorInvalidValue;   // float keys do not travel between passes
+  using K = Cw<P, ND, H, PK, W16, TR>;
   CwArgs a{};
   a.j = j;
   a.nw = pl.nw;
@@ -1435,7 +85,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   a.tile0 = k0;
   const int rows = j.y1 - j.y0;
   static_assert(K::NR == 2 * H + 3 && K::NB == 2 && K::RBW == 72 * P && K::XOFF == ((W16 || K::SWZ) ? 7 : 3), "plan_lds_bytes mirrors Cw");
-  Plan plk = pl; plk.p = P; plk.nd = ND; plk.pk = PK; plk.w16 = W16; plk.fl = FL;
+  Plan plk = pl; plk.p = P; plk.nd = ND; plk.pk = PK; plk.w16 = W16;
   const size_t lds = plan_lds_bytes(plk, H, j.maxdisp) + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
   if (lds > 160 * 1024 || lds < (size_t)(K::NR + 1) * (K::TW + RW) * sizeof(typename K::Px)) return hipErrorInvalidValue;
   if (dry) return hipSuccess;
@@ -1449,7 +99,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   const int min_rows = env_int("SADHIP_TUNE_MINROWS", 8);
   long nstrips;
   bool asked = false;
-  const int per_cu = wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, FL, TR>, 64 * pl.nw, lds, &asked);
+  const int per_cu = wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, TR>, 64 * pl.nw, lds, &asked);
   if (env_int("SADHIP_TUNE_LEGACY_STRIPS", 0)) {                // round 2's constants, for comparison
     const long want = env_int("SADHIP_TUNE_WGS", P == 4 ? 512 : 256);
     const long rows_target = env_int("SADHIP_TUNE_ROWS", 48 * H), wg_max = env_int("SADHIP_TUNE_WGMAX", 4096);
@@ -1487,7 +137,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
       else (void)hipMemsetAsync(aa.stamps, 0, nwg * 16 * 8 * sizeof(unsigned long long), s);
     }
 #endif
-    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, FL, TR>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, TR>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef SADHIP_STAMPS
@@ -1525,30 +175,36 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
 // plan exists AND every pass of it is a kernel this build instantiates and can launch
 static bool passes_launchable(const Job& j, const std::vector<Pass>& passes);
 
-bool fast_supported(const Job& j)
+// The job's passes when the column-wave kernel runs it, nullptr when the generic kernel does.  ONE planning per
+// call: plan_job's memo (three compares for a caller that streams frames with the same parameters) and a dry run
+// of every pass (a few integer checks, no HIP call).
+static const std::vector<Pass>* plan_for(const Job& j)
 {
-  if (j.w < 1 || j.h < 1) return false;
-  if ((j.rw > 0 && j.rw < j.w) || (j.rh > 0 && j.rh < j.h)) return false;   // smaller right image: dropped terms, generic kernel only
-  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2);   // BlockSize 2..31
-  return !passes.empty() && passes_launchable(j, passes);
+  if (j.w < 1 || j.h < 1) return nullptr;
+  if ((j.rw > 0 && j.rw < j.w) || (j.rh > 0 && j.rh < j.h)) return nullptr;   // smaller right image: dropped terms, generic kernel only
+  const std::vector<Pass>& passes = plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2);   // BlockSize 2..31
+  return (!passes.empty() && passes_launchable(j, passes)) ? &passes : nullptr;
 }
+
+bool fast_supported(const Job& j) { return plan_for(j) != nullptr; }
 
 static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry = false, PassGeom* geom = nullptr);
 
 int describe_fast(const Job& j, char* buf, int cap, bool geometry)
 {
   if (buf && cap > 0) buf[0] = 0;
-  if (!fast_supported(j)) return 0;
+  const std::vector<Pass>* planned = plan_for(j);
+  if (!planned) return 0;
+  const std::vector<Pass>& passes = *planned;
   const int h = j.block / 2;
-  const std::vector<Pass> passes = plan_job(h, j.maxdisp, j.w <= j.maxdisp + 2 * h + 2);
   int at = 0;
   for (size_t k = 0; k < passes.size(); ++k) {
     const Plan& pl = passes[k].pl;
     const int next = k + 1 < passes.size() ? passes[k + 1].dbase : j.maxdisp + 1;
     const size_t lds = plan_lds_bytes(pl, h, j.maxdisp);
     if (buf && at < cap)
-      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d fl=%d lds=%zu",
-                     passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, (int)pl.fl, lds);
+      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d lds=%zu",
+                     passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, lds);
     if (geometry) {
       PassGeom g;
       if (launch_pass(j, pl, PassIo{passes[k].dbase, nullptr, nullptr, j.x1 - j.x0}, nullptr, false, &g) != hipSuccess) return -1;
@@ -1563,27 +219,6 @@ int describe_fast(const Job& j, char* buf, int cap, bool geometry)
 static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, PassGeom* geom)
 {
   const int h = j.block / 2;
-#ifdef SADHIP_TUNING            // the float variant is an experiment (slower than the packed kernels): diagnostics build only
-#define SADHIP_FL(HH) if (pl.fl && h == HH) return launch_t<8, 8, HH, false, 1024, false, true>(j, pl, io, s, dry, 0, geom)
-  SADHIP_FL(4); SADHIP_FL(5); SADHIP_FL(6); SADHIP_FL(7);
-#endif
-  if (pl.fl) return hipErrorInvalidValue;
-#ifdef SADHIP_EXPERIMENT        // resource-usage experiments: only the instantiations under study (seconds to compile)
-  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry, 0, geom);
-  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry, 0, geom);
-  if (pl.w16 && !pl.pk && h == 15) return launch_t<8, 8, 15, false, 1024, true>(j, pl, io, s, dry, 0, geom);
-  if (pl.p == 8 && pl.nd == 8 && h == 7 && pl.pk) return launch_t<8, 8, 7, true>(j, pl, io, s, dry, 0, geom);
-  if (pl.p == 8 && pl.nd == 8 && h == 5 && !pl.pk) return launch_t<8, 8, 5, false, 1024>(j, pl, io, s, dry, 0, geom);
-  if (pl.p == 4 && pl.nd == 16 && h == 4 && pl.pk) {
-    const int trmode = kTripleColumns ? env_int("SADHIP_TUNE_TRMODE", 2) : 0;
-    if (trmode == 0 || (trmode == 1 && !dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, 16, 4, true>(j, pl, io, s, dry, 0, geom);
-    if (trmode == 2) return launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 0, geom);
-    const hipError_t e1 = launch_t<4, 16, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1, geom);
-    return e1 != hipSuccess ? e1 : launch_t<4, 16, 4, true>(j, pl, io, s, dry, 2, geom);
-  }
-  if (pl.p == 4 && pl.nd == 16 && h == 7 && pl.pk) return launch_t<4, 16, 7, true>(j, pl, io, s, dry, 0, geom);
-  return hipErrorInvalidValue;
-#else
   if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry, 0, geom);
   if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry, 0, geom);   // 128-VGPR build: two workgroups per CU
 #define SADHIP_W16U(HH) if (pl.w16 && !pl.pk && h == HH) return launch_t<8, 8, HH, false, 1024, true>(j, pl, io, s, dry, 0, geom)
@@ -1595,8 +230,8 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   if (pl.p == 4 && pl.nd == NDD && h == 4 && pl.pk) { \
     const int trmode = kTripleColumns ? env_int("SADHIP_TUNE_TRMODE", 2) : 0;   /* 0 plain, 1 two launches split by tile, 2 one kernel that picks per workgroup */ \
     if (trmode == 0 || (trmode == 1 && !dry && j.n < env_int("SADHIP_TUNE_TRMIN", 48))) return launch_t<4, NDD, 4, true>(j, pl, io, s, dry, 0, geom); \
-    if (trmode == 2) return launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 0, geom); \
-    const hipError_t e1 = launch_t<4, NDD, 4, true, 1024, false, false, true>(j, pl, io, s, dry, 1, geom); \
+    if (trmode == 2) return launch_t<4, NDD, 4, true, 1024, false, true>(j, pl, io, s, dry, 0, geom); \
+    const hipError_t e1 = launch_t<4, NDD, 4, true, 1024, false, true>(j, pl, io, s, dry, 1, geom); \
     return e1 != hipSuccess ? e1 : launch_t<4, NDD, 4, true>(j, pl, io, s, dry, 2, geom); \
   }
 #define SADHIP_P4(NDD) SADHIP_CASE(4, NDD, 1, true); SADHIP_CASE(4, NDD, 2, true); SADHIP_CASE(4, NDD, 3, true); SADHIP_B9(NDD)
@@ -1620,7 +255,6 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   SADHIP_UH(9); SADHIP_UH(10); SADHIP_UH(11); SADHIP_UH(12); SADHIP_UH(13); SADHIP_UH(14); SADHIP_UH(15);   // BlockSize 18..31: two-lane halos
 #undef SADHIP_CASE
   return hipErrorInvalidValue;
-#endif
 }
 
 static bool passes_launchable(const Job& j, const std::vector<Pass>& passes)
@@ -1639,8 +273,9 @@ static bool passes_launchable(const Job& j, const std::vector<Pass>& passes)
 hipError_t launch_fast(const Job& j, hipStream_t s)
 {
   if (j.n <= 0 || j.x1 <= j.x0 || j.y1 <= j.y0) return hipSuccess;
-  if (!fast_supported(j)) return launch_generic(j, s);
-  const std::vector<Pass> passes = plan_job(j.block / 2, j.maxdisp, j.w <= j.maxdisp + 2 * (j.block / 2) + 2);
+  const std::vector<Pass>* planned = plan_for(j);          // planned ONCE per call (round 2: fast_supported + here, each with a dry run)
+  if (!planned) return launch_generic(j, s);                // routed at planning time; a launch error below is returned, never retried
+  const std::vector<Pass>& passes = *planned;
   if (passes.size() == 1) {
     const hipError_t e = launch_pass(j, passes[0].pl, PassIo{0, nullptr, nullptr, 0}, s);
     if (e == hipSuccess) note_launch(KIND_COLWAVE);

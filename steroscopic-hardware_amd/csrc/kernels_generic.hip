@@ -62,8 +62,11 @@ k_disparity_generic(Job j)
 //           d in [0,D] is a candidate; window terms with xr < 0 are skipped (:83-85); strict '<'.
 //   mode 2  hardware/test.py:262-294  both images zero-padded by win/2, the padded right image
 //           shifted by d with zero fill, box sum of |L-R|, strict '<'; output for every pixel.
-//   mode 3  hardware/compute_SAD.v:62-265 (compute_max_disp): the OPPOSITE sign convention -- the
-//           right window slides to LARGER columns (col_index + disp_idx, :213); d runs over
+//   mode 3  the search the Verilog testbench goldens describe (mems/exp_disp_n.mem, old_mems/exp_disp.mem) -- the
+//           INTENDED compute_max_disp of hardware/compute_SAD.v:62-265, not the RTL as written: the RTL shifts in
+//           img_block_R[row][col_index + disp_idx + 1] (:213) where a contiguous window needs column
+//           col_index + WIN + disp_idx, and outputs best_disp - (WIN-1) (:219).  OPPOSITE sign convention: the
+//           right window slides to LARGER columns, contiguously (x + d); d runs over
 //           [0, MAX_DISP) EXCLUSIVE (:206-215); a candidate whose right window would leave the strip
 //           is not searched (the testbench strips are MAX_DISP columns wide, ez_tb.v); strict '<'
 //           (:201-204; the sad == 0 early stop is result-neutral); interior pixels only (the FSM

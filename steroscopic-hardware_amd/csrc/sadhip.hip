@@ -370,7 +370,9 @@ static hipError_t dispatch(const Job& j, unsigned flags, hipStream_t s)
   if (flags & SADHIP_FLAG_MIRROR_SADC) return launch_mirror(j, 1, s);
   if (flags & SADHIP_FLAG_MIRROR_TESTPY) return launch_mirror(j, 2, s);
   if (flags & SADHIP_FLAG_MIRROR_VERILOG) return launch_mirror(j, 3, s);
-  if (!(flags & SADHIP_FLAG_FORCE_GENERIC) && fast_supported(j)) return launch_fast(j, s);
+  // launch_fast plans the job once and routes it to the generic kernel itself when the column-wave kernel has no
+  // plan for it (sadhip_kernel_kind() gives the same answer up front)
+  if (!(flags & SADHIP_FLAG_FORCE_GENERIC)) return launch_fast(j, s);
   return launch_generic(j, s);
 }
 

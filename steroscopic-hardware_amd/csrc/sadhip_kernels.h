@@ -47,7 +47,8 @@ hipError_t launch_generic(const Job& j, hipStream_t s);
 // search of hardware/compute_SAD.v); raw d output.
 hipError_t launch_mirror(const Job& j, int mode, hipStream_t s);
 
-// Fast kernel (kernels_fast.hip): returns true if it supports the job's parameters.
+// Column-wave kernel (colwave_kernel.h, launched from kernels_fast.hip): fast_supported = it has a plan for the job.
+// launch_fast plans once per call and runs the generic kernel itself for a job without a plan.
 bool fast_supported(const Job& j);
 hipError_t launch_fast(const Job& j, hipStream_t s);
 // Text description of the passes launch_fast would run (empty when it would not): see sadhip_plan_describe;

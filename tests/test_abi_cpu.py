@@ -75,7 +75,7 @@ def test_product_library_reads_no_environment():
 
 
 def test_no_column_wave_kernel_spills():
-    """hipcc -Rpass-analysis=kernel-resource-usage over kernels_fast.hip (make remarks): NO instantiation
+    """hipcc -Rpass-analysis=kernel-resource-usage over kernels_fast.hip (the instantiations of colwave_kernel.h; make remarks): NO instantiation
     may use scratch memory or spill a VGPR (round 1: the kernels the reference's default parameters 16/64
     select spilled 14-21 VGPRs, 60-88 bytes of scratch per lane).  SGPR -> VGPR-lane parking (no memory
     traffic) is tolerated only in the lane-mask families (packed h = 6, 7: up to 7 64-bit masks live across
@@ -95,7 +95,7 @@ def test_no_column_wave_kernel_spills():
         name = b.split()[0]
         val = lambda k: int(re.search(k + r": (\d+)", b).group(1))
         sc, ss, vs = val(r"ScratchSize \[bytes/lane\]"), val("SGPRs Spill"), val("VGPRs Spill")
-        m = re.search(r"k_colwaveILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi\d+ELb\dELb\dELb(\d)E", name)
+        m = re.search(r"k_colwaveILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi\d+ELb\dELb(\d)E", name)   # <P, ND, H, PK, WB, W16, TR>
         lane_mask_family = bool(m) and m.group(4) == "1" and m.group(3) in ("6", "7")
         # the BlockSize-9 kernels hold two forms behind a per-workgroup branch (triple-column / plain, Cw::TR3)
         two_form_family = bool(m) and m.group(5) == "1"
@@ -172,7 +172,7 @@ def test_whole_ui_parameter_grid_plans_on_the_fast_kernel():
 
 
 def test_planner_invariants_over_the_parameter_space():
-    """plan_job (kernels_fast.hip) through sadhip_plan_describe: passes tile [0, D] without gaps, stay
+    """plan_job (colwave_plan.hip) through sadhip_plan_describe: passes tile [0, D] without gaps, stay
     inside the launch limits the kernel assumes, and keep the properties the kernel relies on."""
     seen, p4_first = set(), set()
     for block in range(2, 32):
@@ -211,12 +211,12 @@ def test_planner_invariants_over_the_parameter_space():
     for block, maxdisp in ((15, 128), (15, 64), (13, 96), (11, 128), (11, 16)):
         assert [ps["p"] for ps in capi.plan_describe(1920, 1080, block, maxdisp)] == [4]
     assert (7, 8) in p4_first or (6, 8) in p4_first             # ... and fall back to P = 8 for a D without an exact P = 4 plan
-    assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0, fl=0,
+    assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0,
                                                          lds=capi.plan_describe(1920, 1080, 9, 64)[0]["lds"])]
 
 
 def test_block_microbenchmark_still_compiles_against_the_kernel():
-    """tools/ubench/block_bench.hip includes kernels_fast.hip and calls its blocks directly;
+    """tools/ubench/block_bench.hip includes colwave_kernel.h and calls its blocks directly;
     __graft_entry__.build() compiles it, so an interface change in the kernel must not break it."""
     import subprocess
     src = os.path.join(REPO, "tools", "ubench", "block_bench.hip")

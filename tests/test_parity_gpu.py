@@ -300,7 +300,7 @@ def test_every_plan_shape(ctx):
 
 def test_multi_pass_disparity_ranges(ctx):
     """D+1 candidates beyond the 16 waves of a workgroup run as several launches that hand a u32 key
-    per pixel from pass to pass (kernels_fast.hip, plan_job): every UI value of MaxDisparity
+    per pixel from pass to pass (colwave_plan.hip, plan_job): every UI value of MaxDisparity
     (cmd/handlers/params.go:45-52: up to 256) for every BlockSize the column-wave kernel covers,
     and larger ranges, incl. frames whose SADs are the largest possible."""
     rng = np.random.default_rng(11)
@@ -571,7 +571,7 @@ def test_device_resident_batch(ctx):
 
 
 def test_block9_batches_triple_column_form(ctx):
-    """BlockSize 9 runs two forms of the row loop in one kernel (kernels_fast.hip, Cw::TR3): workgroups of the
+    """BlockSize 9 runs two forms of the row loop in one kernel (colwave_kernel.h, Cw::TR3): workgroups of the
     tiles left of the image's last two columns the triple-column form, the rest the plain form.
     Widths around every tile boundary of that choice (258 = one tile + 2, 260 / 508: a triple-form tile whose last
     column is w-5, the closest it gets to the row's end, 506 = two tiles + 2, ...) and every

@@ -1,8 +1,7 @@
 // block_bench.hip -- times the two register-resident blocks of the column-wave kernel in
 // isolation (no LDS/global traffic in the loop) to separate VALU issue cost from everything else.
 //   hipcc --offload-arch=gfx950 -O3 -I../../steroscopic-hardware_amd/csrc -o block_bench block_bench.hip
-#include "../../steroscopic-hardware_amd/csrc/kernels_fast.hip"
-#include "../../steroscopic-hardware_amd/csrc/kernels_generic.hip"
+#include "../../steroscopic-hardware_amd/csrc/colwave_kernel.h"      // device code only: Cw<...> and its blocks
 #include <cstdio>
 using namespace sadhip;
 

@@ -169,13 +169,13 @@ def main():
     ap.add_argument("--asm", default=os.path.join(LIBD, "kernels_fast.s"))
     ap.add_argument("--json")
     ap.add_argument("--blocks", action="store_true")
-    ap.add_argument("-D", dest="defs", action="append", default=[], help="extra -D for the compile (e.g. SADHIP_EXPERIMENT: only the kernels under study)")
+    ap.add_argument("-D", dest="defs", action="append", default=[], help="extra -D for the compile")
     a = ap.parse_args()
     P, ND, H, PK, WB, W16 = (int(v) for v in a.variant[:6])
     TR = int(a.variant[6]) if len(a.variant) > 6 else 0
     ensure_asm(a.asm, a.defs)
     asm = open(a.asm).read()
-    sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb0ELb{TR}EEEvNS0_6CwArgsE"
+    sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb{TR}EEEvNS0_6CwArgsE"   # k_colwave<P, ND, H, PK, WB, W16, TR>
     blocks = analyse(kernel_body(asm, sym, 3 if TR else 1))
     main_ins, xtra_ins = [], []
     # the extra-candidate path = the blocks from the kernel's SADHIP_XTRA_BEGIN marker to its SADHIP_XTRA_END
