@@ -711,22 +711,33 @@ def _props(ctx, L, R, block, maxdisp, flags=0):
 
 def _literal_rows(L, R, block, maxdisp, rows):
     """Full-width rows of the LITERAL restatement of sad.go:55-94 (multithreaded), scaled output."""
-    out = {}
-    for ya, yb in rows:
-        out[(ya, yb)] = oracle.disparity_rows_mt(L, R, block, maxdisp, ya, yb, min(16, os.cpu_count() or 1))
-    return out
+    from concurrent.futures import ThreadPoolExecutor
+    rows = list(rows)
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:      # short ranges: one oracle thread each, ranges in parallel
+        res = list(ex.map(lambda r: oracle.disparity_rows_mt(L, R, block, maxdisp, r[0], r[1], 1), rows))
+    return dict(zip(rows, res))
 
 
-def _seam_rows(h, nstrips_guess, span):
-    """Row ranges across every plausible strip seam (the kernel cuts a frame into 1..8 strips of equal
-    height) plus the frame's top and bottom."""
-    rows = {(0, span), (h - span, h)}
-    for n in nstrips_guess:
-        th = (h + n - 1) // n
-        for k in range(1, n):
-            y = k * th
-            rows.add((max(0, y - span // 2), min(h, y + span // 2)))
-    return sorted(rows)
+def _seam_rows(w, h, block, maxdisp, n=1, span=4):
+    """Row ranges across every REAL strip seam of a launch of n frames, from the library's own launch geometry
+    (sadhip_plan_describe_batch: choose_strips() cuts a frame into strips of `rows` output rows -- 60 to 90 of them for
+    a single 1080p frame, a handful for a long batch -- per pass), plus the frame's top and bottom.  Returns
+    (merged row ranges, passes as (strips, rows))."""
+    geo = capi.plan_describe_batch(w, h, block, maxdisp, n)
+    assert geo and all(g["device"] == 1 for g in geo), geo          # occupancy asked from the runtime of THIS device
+    marks = {(0, span), (h - span, h)}
+    for g in geo:
+        assert (h + g["rows"] - 1) // g["rows"] == g["strips"]
+        for k in range(1, g["strips"]):
+            y = k * g["rows"]
+            marks.add((max(0, y - span // 2), min(h, y + span // 2)))
+    merged = []
+    for ya, yb in sorted(marks):
+        if merged and ya <= merged[-1][1]:
+            merged[-1] = (merged[-1][0], max(merged[-1][1], yb))
+        else:
+            merged.append((ya, yb))
+    return merged, [(g["strips"], g["rows"]) for g in geo]
 
 
 def test_config3_1080p_b9_d64(ctx):
@@ -734,11 +745,11 @@ def test_config3_1080p_b9_d64(ctx):
     got = _props(ctx, L, R, 9, 64)
     sc = ctx.disparity(L, R, 9, 64)
     assert capi.last_kernel_kind() == capi.KIND_COLWAVE
-    # the whole width on >= 64 rows spread over every strip seam, against the literal CPU restatement
-    rows = _seam_rows(1080, (2, 3, 4, 5, 6, 8), 8)
-    assert sum(b - a for a, b in rows) >= 64
+    # the whole width on 2 rows either side of EVERY real strip seam of this launch, against the literal CPU restatement
+    rows, passes = _seam_rows(1920, 1080, 9, 64)
+    assert passes[0][0] >= 8 and sum(b - a for a, b in rows) >= 64, passes
     for (ya, yb), exp in _literal_rows(L, R, 9, 64, rows).items():
-        assert np.array_equal(sc[ya:yb], exp), (ya, yb)
+        assert np.array_equal(sc[ya:yb], exp), (ya, yb, passes)
     for (x0, y0, x1, y1) in ((0, 500, 120, 540), (1800, 300, 1920, 340), (900, 536, 1100, 546)):
         assert np.array_equal(got[y0:y1, x0:x1], oracle.disparity_closed(L, R, 9, 64, region=(x0, y0, x1, y1), raw=True))
     assert np.array_equal(got, ctx.disparity(L, R, 9, 64, capi.FLAG_FORCE_GENERIC | capi.FLAG_RAW))   # two independent kernels agree
@@ -753,10 +764,36 @@ def test_config5_4k_b15_d128(ctx):
     assert np.array_equal(got[700:724], ctx.disparity_region(L, R, 15, 128, band, capi.FLAG_FORCE_GENERIC | capi.FLAG_RAW))
     sc = ctx.disparity(L, R, 15, 128)
     assert capi.last_kernel_kind() == capi.KIND_COLWAVE
-    rows = _seam_rows(2160, (2, 3, 4, 5, 6, 7, 8), 6)          # >= 64 full-width rows over every strip seam, literal oracle
-    assert sum(b - a for a, b in rows) >= 64
+    rows, passes = _seam_rows(3840, 2160, 15, 128)            # 2 rows either side of every real strip seam, literal oracle
+    assert sum(b - a for a, b in rows) >= 64, passes
     for (ya, yb), exp in _literal_rows(L, R, 15, 128, rows).items():
-        assert np.array_equal(sc[ya:yb], exp), (ya, yb)
+        assert np.array_equal(sc[ya:yb], exp), (ya, yb, passes)
+
+
+def test_batched_layout_complete_frames_vs_literal_oracle(ctx):
+    """The batched layout (blockIdx.x = strip + strips * frame, few tall strips) against the LITERAL restatement on
+    COMPLETE frames: 128 device-resident 1080p pairs (config 4's per-GPU shard on 8 GPUs) in one launch; the first,
+    the last and one middle frame compared in full, every other frame on the rows around this launch's strip seams'
+    first seam, and the plan of this batch length is what the seam rows come from (bench.py checks 17 frames of its
+    1024-pair launches the same way, outside the test suite)."""
+    import torch
+    n, W, H, B, D = 128, 1920, 1080, 9, 64
+    seeds = [1000 + 8 * i for i in range(n)]                       # rank 0's shard of config 4 on 8 GPUs
+    parts = [sha.synth.synth_batch_torch(seeds[c:c + 32], W, H, "cuda:0") for c in range(0, n, 32)]
+    Ls, Rs = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]); del parts
+    out = torch.empty_like(Ls)
+    ctx.disparity_dev(Ls, Rs, out, B, D)
+    torch.cuda.synchronize()
+    assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+    rows, passes = _seam_rows(W, H, B, D, n=n)
+    thr = min(16, os.cpu_count() or 1)
+    for i in (0, 61, n - 1):                                       # complete frames
+        L, R = Ls[i].cpu().numpy(), Rs[i].cpu().numpy()
+        assert np.array_equal(out[i].cpu().numpy(), oracle.disparity_rows_mt(L, R, B, D, 0, H, thr)), (i, passes)
+    for i in range(1, n - 1, 9):                                   # the others: around every seam of this launch
+        L, R, o = Ls[i].cpu().numpy(), Rs[i].cpu().numpy(), out[i].cpu().numpy()
+        for ya, yb in rows[:6]:
+            assert np.array_equal(o[ya:yb], oracle.disparity_rows_mt(L, R, B, D, ya, yb, thr)), (i, ya, yb, passes)
 
 
 def test_config4_stream_shard(ctx):
