@@ -269,9 +269,13 @@ struct Cw {                                         // P columns per lane: 4 (pa
   }
   struct Src { const Px* a; const Px* b; };           // operand block of a lane: even quads at a, odd quads at b (SWZ); else all at a
   static constexpr int MAXR = (TW + 4 * ND + 8 + 255) / 256;   // ... R elements per lane
-  static constexpr bool NEED_MASK = PK && H > 5;    // packed h = 6, 7: 2*(2h+1)^2*255 does not fit u16
+  // packed h = 6, 7: 2*(2h+1)^2*255 does not fit u16, so missing candidates are removed by masking keys (lane masks)
+  // instead of penalised start values.  The triple-column form of h = 7 carries NEITHER: k_colwave runs it only in
+  // workgroups where every candidate exists for every output pixel (not the leftmost tiles), so it holds no mask
+  // state at all (with it the two-form kernel spilled 24 SGPRs into VGPR lanes and ran scalar work on the vector ALU).
+  static constexpr bool NEED_MASK = PK && H > 5 && !TR;
   // TR3: "triple-column" form of the packed P = 4 variants whose window width is a multiple of three
-  // (BlockSize 9: h = 4, and BlockSize 3: h = 1).  v_sad_u8 sums FOUR byte lanes, and the plain form
+  // (BlockSize 9: h = 4; BlockSize 15: h = 7, five triples reaching two lanes either way; BlockSize 3: h = 1, not used).  v_sad_u8 sums FOUR byte lanes, and the plain form
   // uses one of them.  Here a ring word of column c holds the pixels c, c+1, c+2 as its three low
   // bytes, so the same instruction accumulates T(x, d) = the column sums of x, x+1, x+2 together, and
   // the (2h+1)-wide window of pixel x is T(x-h) + T(x-h+3) + ... : for h = 4 two additions per column
@@ -286,7 +290,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
   // triple, measured slower in this form: more load traffic per streamed pixel for no arithmetic saved
   // that its small horizontal pass had not saved already.)
   static constexpr bool TR3 = TR;
-  static_assert(!TR || (PK && P == 4 && !W16 && H == 4), "triple-column form: packed P = 4, h = 4");
+  static_assert(!TR || (PK && P == 4 && !W16 && (H == 4 || H == 7)), "triple-column form: packed P = 4, h = 4 or 7 (BlockSize 9, 15)");
   static constexpr int NM = ND + P;                 // lane masks: one per (candidate - column), see run()
   // Mask k is "lanes >= max(0, floor((T0 + k) / P))" for a wave-uniform T0: consecutive k share their
   // mask P at a time, so a wave holds only NMB distinct masks plus one carry bit per residue k % P, and
@@ -481,6 +485,33 @@ struct Cw {                                         // P columns per lane: 4 (pa
         for (int p = 0; p < P; ++p) asm("" : "+v"(s[p]));
         s[2] += from_right(t0);
         s[3] += from_right(t1);
+      } else if constexpr (H == 7 && P == 4) {
+        // BlockSize 15: window of pixel p = T(p-7) + T(p-4) + T(p-1) + T(p+2) + T(p+5), i.e. (lane-relative)
+        //   p = 0:  L2.T1  L1.T0  L1.T3  T2     R1.T1          L1 / L2 = one / two lanes to the left, R1 / R2 to the right
+        //   p = 1:  L2.T2  L1.T1  T0     T3     R1.T2
+        //   p = 2:  L2.T3  L1.T2  T1     R1.T0  R1.T3
+        //   p = 3:  L1.T0  L1.T3  T2     R1.T1  R2.T0
+        // A term two lanes away travels as part of a partial sum built in the lane between (x0, x1, x2: "what my right
+        // neighbour's pixel needs from me and from my left neighbour"), T0 + T3 serves three pixels (its own, and as a
+        // whole the neighbours' on both sides) and T2 + R1.T1 two: 13 instructions per register, 12 of them DPP, against
+        // the 20 of the plain form's prefix / suffix sums and two-hop pulls.  Every partial sum is a subset of ONE pixel's
+        // window, so no u16 half can overflow (15 * 15 * 255 < 65536).
+        const unsigned t0 = r.ps[1], t1 = r.ps[2], t2 = r.ps[3], t3 = r.ps[4];
+        unsigned a = t0 + t3;
+        unsigned x1 = t1 + from_left(t2);
+        unsigned x2 = t2 + from_left(t3);
+        unsigned y = t2 + from_right(t1);
+        unsigned z = from_right(t0);                               // R1.T0, pulled once more below: R2.T0
+        asm("" : "+v"(a), "+v"(x1), "+v"(x2), "+v"(y), "+v"(z));
+        unsigned x0 = a + from_left(t1);
+        s[1] = a + from_right(t2);
+        s[2] = t1 + from_right(a);
+        s[3] = y + from_left(a);
+        asm("" : "+v"(x0), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+        s[0] = y + from_left(x0);
+        s[1] += from_left(x1);
+        s[2] += from_left(x2);
+        s[3] += from_right(z);
       } else {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -723,8 +754,14 @@ struct Cw {                                         // P columns per lane: 4 (pa
     unsigned pfl[MAXL], pfr[MAXR];                        // the row in flight (raw bytes)
     auto load_row = [&](int yy) {
       if (yy >= 0 && yy < j.h) {
-        const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * j.lstride;
-        const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * j.rstride;
+        // TR3 && h = 7: the strides are pinned to scalar registers here.  That kernel runs at the SGPR limit and the
+        // compiler otherwise keeps the two (sign-extended) strides in VGPRs across the loop: the row pointers are then
+        // computed on the vector ALU, the buffer resource looks divergent and EVERY row load becomes a waterfall loop
+        // (4 v_readfirstlane + 2 v_cmp + saveexec per load, ~70 vector instructions per row step in all).
+        const int ls = (TR3 && H > 5) ? __builtin_amdgcn_readfirstlane(j.lstride) : j.lstride;
+        const int rs = (TR3 && H > 5) ? __builtin_amdgcn_readfirstlane(j.rstride) : j.rstride;
+        const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * ls;
+        const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * rs;
         if constexpr (PK) {
           // one resource per row (scalar arithmetic): base = the row, num_records = its width
           const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lrow), 0, j.w, 0x00020000);
@@ -836,7 +873,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
     // tx + P*l + p - h >= dc + j, i.e. l >= ceil((dc + h - tx + (j - p)) / P): one 64-bit lane mask
     // per value of j - p, kept in SGPRs and applied with one v_cndmask_b32 per key.
     constexpr unsigned PEN = PK ? (unsigned)(B1 * B1 * 255) : (1u << 27);
-    constexpr bool use_pen = !NEED_MASK;
+    constexpr bool use_pen = !(PK && H > 5);          // (packed h = 6, 7: key masks, or -- triple form -- nothing to remove)
     // Lane masks (Masks above): NMB distinct 64-bit masks in SGPR pairs + the carry bits, held across the
     // row loop; the mask of a key is a scalar select at its use.  (Measured alternatives, DESIGN.md
     // section 6b: all ND + P masks ready-made cost 32-40 SGPRs, 13-25 of them parked in VGPR lanes; a
@@ -1001,10 +1038,19 @@ struct Cw {                                         // P columns per lane: 4 (pa
 template <int P, int ND, int H, bool PK, int WB, bool W16, bool TR = false>
 __global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
 {
-  if constexpr (TR) {                                         // per workgroup: the tile with the image's last two columns runs the plain form
+  if constexpr (TR) {
+    // per workgroup: the tile with the image's last two columns runs the plain form (Cw::TR3), and for h = 6, 7 so does
+    // every tile with an output pixel x whose window starts left of a candidate of this pass (x - h < d: the plain form
+    // masks those keys; the triple form carries no masks)
     using K = Cw<P, ND, H, PK, W16, true>;
-    const int tx = a.tx0 + ((int)blockIdx.y + a.tile0) * K::STEP;
-    if (tx + K::TW + 2 <= a.j.w) K::run(a); else Cw<P, ND, H, PK, W16, false>::run(a);
+    const int tile = (int)blockIdx.y + a.tile0;
+    const int tx = a.tx0 + tile * K::STEP;
+    bool triple = tx + K::TW + 2 <= a.j.w;
+    if constexpr (PK && H > 5) {
+      const int ox0 = max(tile == 0 ? a.j.x0 : tx + K::OL, a.j.x0);
+      triple = triple && !(max(ox0, 0) - H < min(a.dbase + a.nw * ND, a.j.maxdisp));
+    }
+    if (triple) K::run(a); else Cw<P, ND, H, PK, W16, false>::run(a);
   } else {
     Cw<P, ND, H, PK, W16, false>::run(a);
   }

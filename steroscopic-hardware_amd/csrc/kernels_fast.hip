@@ -239,7 +239,13 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   SADHIP_P4(4); SADHIP_P4(8); SADHIP_P4(12); SADHIP_P4(16); SADHIP_P4(20); SADHIP_P4(24);
   SADHIP_P8(4); SADHIP_P8(8); SADHIP_CASE(8, 12, 5, true);
   // packed P = 4 with two-lane halos (h = 5..7): wide disparity ranges as 8-wave workgroups, two or three per CU
-#define SADHIP_P4H(NDD) SADHIP_CASE(4, NDD, 5, true); SADHIP_CASE(4, NDD, 6, true); SADHIP_CASE(4, NDD, 7, true)
+  // BlockSize 15 (h = 7): its window is five pixel triples -- the same two-form kernel as BlockSize 9 (SADHIP_TUNE_TRMODE=0: plain form)
+#define SADHIP_B15(NDD) \
+  if (pl.p == 4 && pl.nd == NDD && h == 7 && pl.pk) { \
+    if (!kTripleColumns || env_int("SADHIP_TUNE_TRMODE", 2) == 0) return launch_t<4, NDD, 7, true>(j, pl, io, s, dry, 0, geom); \
+    return launch_t<4, NDD, 7, true, 1024, false, true>(j, pl, io, s, dry, 0, geom); \
+  }
+#define SADHIP_P4H(NDD) SADHIP_CASE(4, NDD, 5, true); SADHIP_CASE(4, NDD, 6, true); SADHIP_B15(NDD)
   SADHIP_P4H(4); SADHIP_P4H(8); SADHIP_P4H(12); SADHIP_P4H(16);
 #ifdef SADHIP_TUNING
   SADHIP_CASE(8, 8, 4, true); SADHIP_CASE(8, 12, 4, true);     // forced for comparison (SADHIP_TUNE_P=8)

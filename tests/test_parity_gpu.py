@@ -570,38 +570,56 @@ def test_device_resident_batch(ctx):
         assert np.array_equal(out[i].cpu().numpy(), _expect(L, R, 9, 64))
 
 
-def test_block9_batches_triple_column_form(ctx):
-    """BlockSize 9 runs two forms of the row loop in one kernel (colwave_kernel.h, Cw::TR3): workgroups of the
-    tiles left of the image's last two columns the triple-column form, the rest the plain form.
-    Widths around every tile boundary of that choice (258 = one tile + 2, 260 / 508: a triple-form tile whose last
-    column is w-5, the closest it gets to the row's end, 506 = two tiles + 2, ...) and every
-    w mod 4, single- and multi-pass disparity ranges, random / shifted / extreme / flat frames, a region;
-    every frame against the oracle or the generic kernel (itself pinned to the oracle above)."""
+_TR_SHAPES = {
+    # BlockSize 9 (tile 256 columns, step 248): 258 = one tile + 2, 260 / 508: a triple-form tile whose last column is w-5, the
+    # closest it gets to the row's end, 506 = two tiles + 2, ... and every w mod 4
+    9: ((257, 20, 16), (258, 20, 64), (259, 22, 64), (260, 20, 64), (261, 20, 64), (505, 20, 64), (506, 20, 64), (507, 21, 33),
+        (508, 20, 64), (600, 24, 128), (745, 20, 64), (1001, 18, 64), (530, 20, 200), (1920, 12, 64)),
+    # BlockSize 15 (tile 256 columns, step 240, two-lane halos): 498 = step + tile + 2, 738 = two steps + tile + 2; the leftmost
+    # tile always runs the plain form (it masks keys), with D 256 (second pass: candidates up to 256 > 248 - 7) so does the
+    # second tile; D 16 .. 256 also walks the chunk sizes 4, 8, 12, 16
+    15: ((257, 34, 16), (258, 34, 64), (261, 34, 64), (496, 34, 64), (497, 33, 64), (498, 34, 64), (499, 34, 128), (500, 34, 32),
+         (501, 36, 64), (737, 34, 48), (738, 34, 128), (740, 34, 64), (742, 34, 256), (1001, 32, 128), (1300, 32, 256), (3840, 30, 128)),
+}
+
+
+@pytest.mark.parametrize("block", sorted(_TR_SHAPES))
+def test_batches_triple_column_form(ctx, block):
+    """BlockSize 9 and 15 run two forms of the row loop in one kernel (colwave_kernel.h, Cw::TR3): the triple-column
+    form in the workgroups of the tiles left of the image's last two columns (BlockSize 15: and right of every pixel
+    that lacks a candidate of the pass -- the triple form carries no key masks), the plain form in the rest.
+    Widths around every tile boundary of that choice and every w mod 4, single- and multi-pass disparity ranges,
+    random / shifted / extreme / flat frames; every frame against the generic kernel (itself pinned to the oracle
+    above) and four of them against the oracle itself."""
     import torch
-    n = 64
-    rng = np.random.default_rng(909)
-    for w, h, D in ((257, 20, 16), (258, 20, 64), (259, 22, 64), (260, 20, 64), (261, 20, 64), (505, 20, 64), (506, 20, 64), (507, 21, 33),
-                    (508, 20, 64), (600, 24, 128),
-                    (745, 20, 64), (1001, 18, 64), (530, 20, 200), (1920, 12, 64)):
+    n = 64 if block == 9 else 24
+    rng = np.random.default_rng(909 + block)
+    for w, h, D in _TR_SHAPES[block]:
         Lb = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
         Rb = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
         s = min(D, 37)
         Rb[1] = np.roll(Lb[1], -s, axis=1)                      # a true shift
-        Lb[2] = 255; Rb[2] = 0; Rb[2][:, w // 2:] = 255         # the largest possible SADs
+        Lb[2] = 255; Rb[2] = 0; Rb[2][:, w // 2:] = 255         # the largest possible SADs (15 * 15 * 255 = 57 375 < 2^16)
         Lb[3] = 77; Rb[3] = 77                                   # flat: every candidate ties
         Rb[4] = Lb[4]                                            # identical: SAD 0 at d = 0
+        Lb[5] = 255; Rb[5] = 0                                   # every window at the maximum: ties at the largest keys
         Ls, Rs = torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda()
         out = torch.full_like(Ls, 0xCD)
         ref = torch.full_like(Ls, 0xEE)
         raw = capi.FLAG_RAW if D <= 255 else 0
-        ctx.disparity_dev(Ls, Rs, out, 9, D, raw)
+        ctx.disparity_dev(Ls, Rs, out, block, D, raw)
         assert capi.last_kernel_kind() == capi.KIND_COLWAVE
-        ctx.disparity_dev(Ls, Rs, ref, 9, D, raw | capi.FLAG_FORCE_GENERIC)
+        ctx.disparity_dev(Ls, Rs, ref, block, D, raw | capi.FLAG_FORCE_GENERIC)
         torch.cuda.synchronize()
         got, exp = out.cpu().numpy(), ref.cpu().numpy()
-        assert np.array_equal(got, exp), (w, h, D, np.argwhere(got != exp)[:4])
+        assert np.array_equal(got, exp), (block, w, h, D, np.argwhere(got != exp)[:4])
         for i in (0, 1, 2, n - 1):                               # and against the oracle itself
-            assert np.array_equal(got[i], _expect(Lb[i], Rb[i], 9, D, raw=bool(raw))), (w, D, i)
+            assert np.array_equal(got[i], _expect(Lb[i], Rb[i], block, D, raw=bool(raw))), (block, w, D, i)
+        # a single frame and a region of one (other strip counts, other output origin)
+        one = ctx.disparity(Lb[0], Rb[0], block, D, raw)
+        assert np.array_equal(one, got[0]), (block, w, D)
+        reg = (w // 3, 3, w - 1, h - 2)
+        assert np.array_equal(ctx.disparity_region(Lb[1], Rb[1], block, D, reg, raw), got[1][reg[1]:reg[3], reg[0]:reg[2]]), (block, w, D)
 
 
 def test_multi_pass_batch_beyond_one_grid(ctx):
