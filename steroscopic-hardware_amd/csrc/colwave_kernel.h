@@ -537,6 +537,40 @@ struct Cw {                                         // P columns per lane: 4 (pa
           if (i >= P) s[p] += from_right(r.ps[i - P + 1]);
         }
       }
+    } else if constexpr (H == P && P == 8) {
+      // BlockSize 16 / 17 (the reference's default parameters): every window holds the whole lane, the last 8-p columns of
+      // the left lane and the first p+1 of the right one.  suffix[8-p] of the left lane = its total - its prefix[p], so
+      //   W(p) = (total + left.total) + right.prefix[p+1] - left.prefix[p]:
+      // no suffix sums at all (7 subtractions per candidate less) and one DPP add for the shared base -- 23 instructions
+      // per candidate instead of 30.  Exact modulo 2^32 like every other sum here (penalised columns included).
+      // The two subtractions are written as  n = left.prefix[p] - base ;  W = right.prefix[p+1] - n  in inline asm:
+      // on this toolchain v_subrev_u32_dpp D, S0, S1 computes dpp(S1) - S0 (tools/ubench/dpp_sub.hip), NOT S1 - dpp(S0)
+      // as hipcc assumes when it folds `base - dpp(x)` into it -- a silent miscompile (every key wrong); in both
+      // subtract forms the lane-shifted operand is the minuend, and v_sub_u32_dpp D = dpp(S0) - S1 is as documented.
+      // (s_nop 1: a DPP source needs two wait states after the VALU instruction that wrote it, and the compiler does
+      // not look into asm.)
+      unsigned base = r.ps[P] + from_left(r.ps[P]);
+      asm("" : "+v"(base));
+      s[0] = base + from_right(r.ps[1]);
+      unsigned n[P];
+#define SADHIP_DPPSUB(SHIFT) \
+      "s_nop 1\n\t" \
+      "v_sub_u32_dpp %0, %7, %14 " SHIFT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_sub_u32_dpp %1, %8, %15 " SHIFT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_sub_u32_dpp %2, %9, %16 " SHIFT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_sub_u32_dpp %3, %10, %17 " SHIFT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_sub_u32_dpp %4, %11, %18 " SHIFT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_sub_u32_dpp %5, %12, %19 " SHIFT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_sub_u32_dpp %6, %13, %20 " SHIFT " row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      asm(SADHIP_DPPSUB("wave_shr:1")                            // n[p] = left.prefix[p] - base
+          : "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]), "=&v"(n[6]), "=&v"(n[7])
+          : "v"(r.ps[1]), "v"(r.ps[2]), "v"(r.ps[3]), "v"(r.ps[4]), "v"(r.ps[5]), "v"(r.ps[6]), "v"(r.ps[7]),
+            "v"(base), "v"(base), "v"(base), "v"(base), "v"(base), "v"(base), "v"(base));
+      asm(SADHIP_DPPSUB("wave_shl:1")                            // W(p) = right.prefix[p+1] - n[p]
+          : "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7])
+          : "v"(r.ps[2]), "v"(r.ps[3]), "v"(r.ps[4]), "v"(r.ps[5]), "v"(r.ps[6]), "v"(r.ps[7]), "v"(r.ps[8]),
+            "v"(n[1]), "v"(n[2]), "v"(n[3]), "v"(n[4]), "v"(n[5]), "v"(n[6]), "v"(n[7]));
+#undef SADHIP_DPPSUB
     } else if constexpr (H <= P) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -758,8 +792,11 @@ struct Cw {                                         // P columns per lane: 4 (pa
         // compiler otherwise keeps the two (sign-extended) strides in VGPRs across the loop: the row pointers are then
         // computed on the vector ALU, the buffer resource looks divergent and EVERY row load becomes a waterfall loop
         // (4 v_readfirstlane + 2 v_cmp + saveexec per load, ~70 vector instructions per row step in all).
-        const int ls = (TR3 && H > 5) ? __builtin_amdgcn_readfirstlane(j.lstride) : j.lstride;
-        const int rs = (TR3 && H > 5) ? __builtin_amdgcn_readfirstlane(j.rstride) : j.rstride;
+        // (The unpacked kernels, at their 128-VGPR / SGPR limits, do the same: pinned, their per-lane byte loads take a
+        // scalar row base + a 32-bit lane offset instead of a 64-bit vector address each.)
+        constexpr bool PIN_STRIDES = (TR3 && H > 5) || !PK;
+        const int ls = PIN_STRIDES ? __builtin_amdgcn_readfirstlane(j.lstride) : j.lstride;
+        const int rs = PIN_STRIDES ? __builtin_amdgcn_readfirstlane(j.rstride) : j.rstride;
         const uint8_t* lrow = Lg + (size_t)(yy - j.row0) * ls;
         const uint8_t* rrow = Rg + (size_t)(yy - j.row0) * rs;
         if constexpr (PK) {

@@ -104,6 +104,22 @@ def test_no_column_wave_kernel_spills():
     assert not bad, bad
 
 
+def test_no_kernel_contains_a_folded_dpp_reverse_subtract():
+    """On this toolchain `v_subrev_u32_dpp D, S0, S1` computes dpp(S1) - S0 on the hardware (tools/ubench/dpp_sub.hip,
+    run on the MI355X box), while hipcc folds `base - dpp(x)` into it as if it were S1 - dpp(S0): every key of the
+    BlockSize-16 kernel came out wrong in round 3.  The kernels write such subtractions as v_sub_u32_dpp in inline asm;
+    this test fails if the compiler ever emits the reversed DPP form (any type) into a column-wave kernel again."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import valu_budget
+    asm_path = os.path.join(REPO, "steroscopic-hardware_amd", "lib", "kernels_fast.s")
+    valu_budget.ensure_asm(asm_path)
+    bad = [l.strip() for l in open(asm_path) if re.match(r"\s*v_subrev\w*_dpp\b", l) or re.match(r"\s*v_subbrev\w*_dpp\b", l)]
+    assert not bad, bad[:5]
+    assert sum(1 for l in open(asm_path) if "v_sub_u32_dpp" in l) >= 14            # the h = 8 kernels' suffix-free window sums
+
+
 def test_null_and_bad_args_are_status_codes_not_crashes():
     l = capi.lib()
     assert l.sadhip_device_count(None) == capi.ERR_NULL
