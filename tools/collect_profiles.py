@@ -43,6 +43,7 @@ def num(pat):
     return float(m.group(1)) if m else None
 
 
+frames = int(num(r"Dmax \d+, (\d+) device-resident pairs per launch") or 0)
 fetch = num(r"\| pmc_fetch \| FETCH_SIZE \| ([\d.e+]+) \|")
 write = num(r"\| pmc_write \| WRITE_SIZE \| ([\d.e+]+) \|")
 insts = num(r"\| pmc_sq \| SQ_INSTS_VALU \| ([\d.e+]+) \|")
@@ -50,7 +51,7 @@ tj = {"_comment": "HBM traffic and VALU instruction count of one batched launch 
                   "from rocprofv3 --pmc (separate passes; profiles/%s_c3.md). gfx950 correction per MI355X_MICROARCH.md "
                   "(FETCH_SIZE x2, WRITE_SIZE x1; re-calibrated in round 1 on known-byte kernels, tools/ubench/hbm_calib.hip)." % tag,
       "round": int(re.sub(r"\D", "", tag) or 0), "source": f"profiles/{tag}_c3.md", "source_digest": digest,
-      "frames_per_launch": 256, "width": 1920, "height": 1080, "block": 9, "maxdisp": 64,
+      "frames_per_launch": frames, "width": 1920, "height": 1080, "block": 9, "maxdisp": 64,
       "fetch_size_kb": fetch, "write_size_kb": write, "fetch_correction": 2.0, "write_correction": 1.0,
       "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "sq_insts_valu_per_launch": int(insts)}
 json.dump(tj, open(os.path.join(pr, "traffic.json"), "w"), indent=1)
