@@ -246,7 +246,10 @@ SADHIP_API int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, 
  * device (a Go caller wraps it with unsafe.Slice as image.Gray.Pix -- C memory, not Go memory);
  * sadhip_host_register page-locks memory the caller already owns (C / C++ hosts only: NEVER Go heap
  * memory) until sadhip_host_unregister.  Every host-buffer entry point recognises pointers inside such
- * ranges and then uses asynchronous linear copies; results are identical either way. */
+ * ranges and then uses asynchronous linear copies; results are identical either way.  Free / unregister a
+ * range only when no call that was given pointers into it is still running (every entry point has finished
+ * with the caller's memory when it returns); a range that disappears under a running call is not an error --
+ * the copies fall back to the pageable path -- but its memory must of course stay valid. */
 SADHIP_API int sadhip_host_alloc(size_t bytes, void** out);
 SADHIP_API int sadhip_host_free(void* p);
 SADHIP_API int sadhip_host_register(void* p, size_t bytes);

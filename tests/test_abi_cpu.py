@@ -104,6 +104,33 @@ def test_no_column_wave_kernel_spills():
     assert not bad, bad
 
 
+def test_abi3_entry_points_validate_and_fail_loudly_without_a_gpu():
+    """sadhip_disparity_lr_u8 / sadhip_host_* / sadhip_plan_describe_batch: status codes, never a crash; without a
+    device the host-memory calls report it (no silent malloc fallback) and the batch plan says device=0."""
+    l = capi.lib()
+    assert l.sadhip_disparity_lr_u8(None, None, 8, 8, 8, None, 8, 8, 8, 7, 32, 0, 0, 0, 8, 8, None, 8) == capi.ERR_NULL
+    assert l.sadhip_host_free(None) == capi.ERR_NULL and l.sadhip_host_unregister(None) == capi.ERR_NULL
+    assert l.sadhip_host_register(None, 16) == capi.ERR_NULL and l.sadhip_host_alloc(16, None) == capi.ERR_NULL
+    p = C.c_void_p()
+    assert l.sadhip_host_alloc(0, C.byref(p)) == capi.ERR_ARG
+    junk = np.zeros(64, np.uint8)
+    assert l.sadhip_host_free(junk.ctypes.data) == capi.ERR_ARG               # not ours
+    assert l.sadhip_host_unregister(junk.ctypes.data) == capi.ERR_ARG
+    assert l.sadhip_host_register(junk.ctypes.data, 0) == capi.ERR_ARG
+    if not _has_gpu():
+        st = l.sadhip_host_alloc(4096, C.byref(p))
+        assert st in (capi.ERR_NO_DEVICE, capi.ERR_HIP) and not p.value, st
+        assert l.sadhip_host_register(junk.ctypes.data, 64) in (capi.ERR_NO_DEVICE, capi.ERR_HIP)
+    geo = capi.plan_describe_batch(1920, 1080, 9, 64, 128)
+    assert len(geo) == 1 and geo[0]["tiles"] == 8 and geo[0]["strips"] >= 1 and (1080 + geo[0]["rows"] - 1) // geo[0]["rows"] == geo[0]["strips"]
+    assert geo[0]["device"] == (1 if _has_gpu() else 0)
+    assert {k: v for k, v in geo[0].items() if k in ("p", "nd", "nw", "packed")} == {k: v for k, v in capi.plan_describe(1920, 1080, 9, 64)[0].items() if k in ("p", "nd", "nw", "packed")}
+    buf = C.create_string_buffer(64)
+    assert l.sadhip_plan_describe_batch(1920, 1080, 9, 64, 0, buf, 64) == -1      # n < 1
+    assert l.sadhip_plan_describe_batch(1920, 1080, 9, 0, 4, buf, 64) == -1       # MaxDisparity 0
+    assert capi.plan_describe_batch(1920, 1080, 40, 64, 4) == []                  # generic kernel: no passes
+
+
 def test_no_kernel_contains_a_folded_dpp_reverse_subtract():
     """On this toolchain `v_subrev_u32_dpp D, S0, S1` computes dpp(S1) - S0 on the hardware (tools/ubench/dpp_sub.hip,
     run on the MI355X box), while hipcc folds `base - dpp(x)` into it as if it were S1 - dpp(S0): every key of the
