@@ -226,6 +226,36 @@ def test_edge_shapes(ctx, w, h, block, maxdisp, flags):
                           np.minimum(_expect(L, R, block, maxdisp, raw=True), 255))
 
 
+def test_maximum_parameters():
+    """The largest parameters the ABI accepts (SADHIP_MAX_BLOCK 255, SADHIP_MAX_MAXDISP 4096) and one past them:
+    a 32-pass column-wave job (4097 candidates, keys travelling from pass to pass), the same range on a frame
+    narrower than it, and a window larger than the image -- against the generic kernel and, on a few rows, the oracle."""
+    rng = np.random.default_rng(4096)
+    W, H, D = 4300, 14, capi.MAX_MAXDISP
+    ctx = capi.Context(0, W, 64, 1)                                                              # wider than the shared fixture's frames
+    L = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    R = np.roll(L, -1500, axis=1) ^ (rng.integers(0, 32, (H, W), dtype=np.uint8) == 0).astype(np.uint8)   # true disparity 1500
+    got = ctx.disparity(L, R, 9, D)
+    assert capi.last_kernel_kind() == capi.kernel_kind(W, H, 9, D) == capi.KIND_COLWAVE and len(capi.plan_describe(W, H, 9, D)) >= 32
+    assert np.array_equal(got, ctx.disparity(L, R, 9, D, capi.FLAG_FORCE_GENERIC))
+    assert np.array_equal(got[6:8], oracle.disparity_closed(L, R, 9, D, region=(0, 6, W, 8)))
+    assert (got[:, 3000:4000] == 1500 * 255 // D).mean() > 0.9                                  # and it finds the shift
+    narrow_L, narrow_R = np.ascontiguousarray(L[:, :700]), np.ascontiguousarray(R[:, :700])    # W < D: every pixel has x - h + 1 candidates
+    for block in (3, 9):
+        g = ctx.disparity(narrow_L, narrow_R, block, D)
+        assert np.array_equal(g, ctx.disparity(narrow_L, narrow_R, block, D, capi.FLAG_FORCE_GENERIC)), block
+        assert np.array_equal(g[3:5], oracle.disparity_literal(narrow_L, narrow_R, block, D, region=(0, 3, 700, 5))), block
+    small_L, small_R = sha.synth.synth_pair(255, 96, 40)
+    g = ctx.disparity(small_L, small_R, capi.MAX_BLOCK, 64)                                     # window 255 x 255 > the image
+    assert capi.last_kernel_kind() == capi.KIND_GENERIC
+    assert np.array_equal(g, oracle.disparity_literal(small_L, small_R, capi.MAX_BLOCK, 64))
+    for block, maxdisp, status in ((capi.MAX_BLOCK + 1, 64, capi.ERR_BLOCK), (9, capi.MAX_MAXDISP + 1, capi.ERR_MAXDISP)):
+        with pytest.raises(capi.SadHipError) as e:
+            ctx.disparity(small_L, small_R, block, maxdisp)
+        assert e.value.status == status
+    ctx.close()
+
+
 def test_random_parameter_sweep(ctx):
     """60 seeded random (w, h, BlockSize, MaxDisparity) draws over the ranges the WebUI allows and
     beyond (cmd/handlers/params.go:37-52: block 3..31 odd, maxDisp 16..256 step 16), every kernel
