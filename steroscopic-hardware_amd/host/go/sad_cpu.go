@@ -28,6 +28,11 @@ func RunSadFrame(left, right *image.Gray, p Parameters) *image.Gray {
 	return runSadGo(left, right, p.BlockSize, p.MaxDisparity)
 }
 
+// NewPinnedGray is image.NewGray in this build (the hip build returns page-locked memory); free is a no-op.
+func NewPinnedGray(r image.Rectangle) (img *image.Gray, free func()) {
+	return image.NewGray(r), func() {}
+}
+
 // AssembleDisparityMap assembles the disparity map from output chunks (sad.go:172-202).
 func AssembleDisparityMap(outputChan <-chan OutputChunk, dimensions image.Rectangle, chunks int) *image.Gray {
 	return assembleDisparityMapGo(outputChan, dimensions, chunks)

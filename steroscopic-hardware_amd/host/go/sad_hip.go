@@ -209,6 +209,24 @@ func RunSadFrame(left, right *image.Gray, p Parameters) *image.Gray {
 	return out
 }
 
+// NewPinnedGray returns an *image.Gray whose Pix lives in page-locked memory from sadhip_host_alloc (C memory,
+// not Go heap memory, so it may stay pinned across calls) and the function that frees it.  Frames a capture pipeline
+// fills in such images (pkg/camera/serial.go reads one 1920x1080 gray frame per UART transfer) reach the device with
+// asynchronous copies at bus speed; everything else about the image is ordinary.  Falls back to image.NewGray when
+// the allocation fails.  Call free only when no RunSad / pipeline chunk using the image is in flight.
+func NewPinnedGray(r image.Rectangle) (img *image.Gray, free func()) {
+	n := r.Dx() * r.Dy()
+	if n <= 0 {
+		return image.NewGray(r), func() {}
+	}
+	var p unsafe.Pointer
+	if st := C.sadhip_host_alloc(C.size_t(n), &p); st != C.SADHIP_OK {
+		return image.NewGray(r), func() {}
+	}
+	pix := unsafe.Slice((*uint8)(p), n)
+	return &image.Gray{Pix: pix, Stride: r.Dx(), Rect: r}, func() { C.sadhip_host_free(p) }
+}
+
 // AssembleDisparityMap assembles the disparity map from output chunks (sad.go:172-202).
 // Unlike the reference it writes all `chunks` chunks (the reference breaks before writing the
 // last one it receives, sad.go:181-184, leaving one rectangle black).

@@ -36,7 +36,7 @@ def test_go_shim_and_patches_are_reviewable():
     hip = open(os.path.join(GO, "sad_hip.go")).read()
     cpu = open(os.path.join(GO, "sad_cpu.go")).read()
     assert hip.startswith("//go:build cgo && hip") and cpu.startswith("//go:build !(cgo && hip)")
-    for name in ("func SetupConcurrentSAD(", "func RunSad(", "func RunSadFrame(", "func AssembleDisparityMap(", "FrameLevel"):
+    for name in ("func SetupConcurrentSAD(", "func RunSad(", "func RunSadFrame(", "func NewPinnedGray(", "func AssembleDisparityMap(", "FrameLevel"):
         assert name in hip and name in cpu, name
     assert "cpuRegion" not in hip and "SumAbsoluteDifferences(" not in hip        # no restated reference loop
     for ref in ("setupConcurrentSADGo(", "runSadGo("):
