@@ -39,12 +39,13 @@ VECTOR_PEAK_GWINST = SIMDS * CLOCK_GHZ / 2     # one wave-instruction per 2 cycl
 
 
 def _source_digest():
-    """sha256 over the kernel sources: what profiles/*.json were measured on (tools/valu_budget.py)."""
+    """sha256 over the KERNEL sources (device code, planner, launch table, generic kernels -- not sadhip.hip, the
+    C-ABI host plumbing, which changes no kernel): what profiles/*.json were measured on (tools/valu_budget.py)."""
     import hashlib
     csrc = os.path.join(REPO, "steroscopic-hardware_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".h", ".inc")):
+        if f.endswith((".hip", ".h", ".inc")) and f != "sadhip.hip":
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -309,11 +309,12 @@ class Context:
         assert all(a.strides[0] == ls for a in lefts) and all(a.strides[0] == rs for a in rights)
         if outs is None:
             outs = [np.empty((h, w), np.uint8) for _ in range(n)]
-        assert len(outs) == n and all(o.shape == (h, w) and o.strides == (w, 1) for o in outs)
+        os_ = outs[0].strides[0]                                     # one row stride for all outputs (>= w: column windows allowed)
+        assert len(outs) == n and all(o.shape == (h, w) and o.strides == (os_, 1) for o in outs) and os_ >= w
         pa = (C.c_void_p * n)(*[a.ctypes.data for a in lefts])
         pb = (C.c_void_p * n)(*[a.ctypes.data for a in rights])
         po = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
-        _check(lib().sadhip_disparity_batch_u8(self._h, n, pa, pb, w, h, ls, rs, block, maxdisp, flags, po, w))
+        _check(lib().sadhip_disparity_batch_u8(self._h, n, pa, pb, w, h, ls, rs, block, maxdisp, flags, po, os_))
         return outs
 
     def sad_windows(self, left, right, block, queries):

@@ -613,6 +613,15 @@ static int batch_pinned(sadhip_ctx* c, int n, const uint8_t* const* lefts, const
     }
     return SADHIP_OK;
   };
+  // Results: a linear copy also carries the bytes BETWEEN rows, which on the way down would overwrite whatever the
+  // caller keeps there (an output that is a column window of a wider image: ostride > w) -- linear only for tight
+  // rows, a 2-D copy per frame otherwise.  (On the way up the extra bytes are merely read, inside a verified range.)
+  auto download = [&](hipStream_t st, const uint8_t* dev, int i0, int cnt) -> int {
+    if (ostride == w) return copy_runs(st, const_cast<uint8_t*>(dev), outs, i0, cnt, fo, co, false);
+    for (int i = 0; i < cnt; ++i)
+      HIPTRY(hipMemcpy2DAsync(outs[i0 + i], (size_t)ostride, dev + (size_t)i * fo, (size_t)ostride, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, st));
+    return SADHIP_OK;
+  };
   auto body = [&]() -> int {
     for (int g = 0; g < ng; ++g) {
       sadhip_ctx::GroupSlot& s = c->grp[g % S];
@@ -639,7 +648,7 @@ static int batch_pinned(sadhip_ctx* c, int n, const uint8_t* const* lefts, const
       HIPTRY(dispatch(j, flags, c->s_kern));
       HIPTRY(hipEventRecord(s.k1, c->s_kern));
       HIPTRY(hipStreamWaitEvent(c->s_down, s.k1, 0));
-      if (int st = copy_runs(c->s_down, s.dO, outs, i0, cnt, fo, co, false)) return st;
+      if (int st = download(c->s_down, s.dO, i0, cnt)) return st;
       HIPTRY(hipEventRecord(s.down, c->s_down));
     }
     for (int g = ng > S ? ng - S : 0; g < ng; ++g) {            // the groups still in flight

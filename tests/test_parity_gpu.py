@@ -559,6 +559,18 @@ def test_page_locked_host_memory_paths(ctx):
         Ls, Rs = pairs[1][0][:, :250], pairs[1][1][:, :250]
         wide[:H, :250], wide[H:, :250] = Ls, Rs
         assert np.array_equal(ctx.disparity(wide[:H, :250], wide[H:, :250], B, D), _expect(np.ascontiguousarray(Ls), np.ascontiguousarray(Rs), B, D))
+        # 5b. strided rows in a batch: inputs AND outputs are column windows of wider page-locked images; nothing outside
+        #     an output window may be touched (a linear download would carry the bytes between rows)
+        wide3 = hb.view((3, 6, H, W))
+        win = slice(20, 20 + 250)
+        for i in range(6):
+            wide3[0, i] = pairs[i][0]; wide3[1, i] = pairs[i][1]
+        wide3[2] = 0xA5
+        outs = ctx.disparity_batch([wide3[0, i][:, win] for i in range(6)], [wide3[1, i][:, win] for i in range(6)], B, D,
+                                   outs=[wide3[2, i][:, win] for i in range(6)])
+        for i in range(6):
+            assert np.array_equal(wide3[2, i][:, win], _expect(np.ascontiguousarray(pairs[i][0][:, win]), np.ascontiguousarray(pairs[i][1][:, win]), B, D)), i
+            assert (wide3[2, i][:, :20] == 0xA5).all() and (wide3[2, i][:, 270:] == 0xA5).all(), i       # untouched
         # 6. the pool over page-locked frames (two contexts on this GPU)
         for i, (l, r) in enumerate(pairs):
             blk[0, i], blk[1, i] = l, r
