@@ -21,7 +21,7 @@ tag = sys.argv[1]
 go, pr = os.path.join(REPO, "gpurun_out"), os.path.join(REPO, "profiles")
 os.makedirs(pr, exist_ok=True)
 for name in sorted(os.listdir(go)):
-    if name.startswith(tag + "_") and name.endswith((".md", ".json")):
+    if name.startswith(tag + "_") and (name.endswith(".md") or name == tag + "_bench_line.json"):    # summaries + the bench line, not scratch outputs
         shutil.copy(os.path.join(go, name), os.path.join(pr, name))
         print("profiles/" + name)
 st = os.path.join(go, f"prof_{tag}_bench", "trace", "trace_kernel_stats.csv")
