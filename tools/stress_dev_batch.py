@@ -18,7 +18,7 @@ for i in range(ncases):
     n = int(rng.integers(1, 9)); w = int(rng.integers(40, 1400)); h = int(rng.integers(8, 200))
     block = int(rng.integers(2, 32)); D = int(rng.choice([16, 32, 64, 65, 100, 128, 200, 256]))
     if i % 3 == 1:                                              # the BlockSize-9 tile split (>= 48 pairs): two kernels per pass
-        block = int(rng.choice([8, 9])); n = int(rng.choice([48, 49, 64, 77])); w = int(rng.integers(250, 1400)); h = int(rng.integers(8, 40))
+        block = int(rng.choice([8, 9, 14, 15, 15, 16, 17])); n = int(rng.choice([3, 24, 48, 49, 64, 77])); w = int(rng.integers(250, 1400)); h = int(rng.integers(8, 40))
     padw = int(rng.integers(0, 70)); padh = int(rng.integers(0, 9))
     big_l = torch.randint(0, 256, (n, h + padh, w + padw), dtype=torch.uint8, device=dev)
     big_r = torch.randint(0, 256, (n, h + padh, w + padw), dtype=torch.uint8, device=dev)

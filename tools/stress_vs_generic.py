@@ -19,6 +19,9 @@ for i in range(ncases):
     w = int(rng.choice([rng.integers(1, 64), rng.integers(64, 600), rng.integers(600, 2100)]))
     h = int(rng.choice([rng.integers(1, 20), rng.integers(20, 120), rng.integers(120, 260)]))
     block = int(rng.integers(1, 34))
+    if rng.random() < 0.3:                                      # round 3's new forms: BlockSize 15 (two-form, h = 7), 16 / 17 (suffix-free window sums), 9
+        block = int(rng.choice([9, 14, 15, 15, 16, 16, 17]))
+        w = int(rng.choice([w, rng.integers(240, 800), rng.integers(800, 4000)]))
     D = int(rng.choice([rng.integers(1, 20), rng.choice([16, 32, 48, 64, 96, 128, 160, 192, 256]), rng.integers(20, 400)]))
     style = int(rng.integers(0, 6))
     if style == 0:
