@@ -62,3 +62,29 @@ def testdata_pair():
 def testdata_rgba():
     from PIL import Image
     return tuple(np.array(Image.open(os.path.join(GOLDEN, n))) for n in ("L_00001.png", "R_00001.png"))
+
+
+def load_real_pixels(name):
+    """A picture of tests/golden/ as the u8 pixel array a Go decoder would hold (h, w, 4 or 3)."""
+    from PIL import Image
+    im = Image.open(os.path.join(GOLDEN, name))
+    assert im.mode in ("RGBA", "RGB")
+    return np.array(im)
+
+
+def load_real_gray(name):
+    """... and its gray plane by the Go formula the reference's callers apply (pkg/camera/output.go:142-162,
+    pkg/despair/gray.go:43-58): 8-bit RGBA files decode to *image.NRGBA, opaque RGB files to *image.RGBA."""
+    import oracle
+    a = load_real_pixels(name)
+    return oracle.gray_from_nrgba(a) if a.shape[2] == 4 else oracle.gray_from_rgb8(a)
+
+
+def _real_pairs():
+    import json
+    with open(os.path.join(GOLDEN, "real_pairs.json")) as f:
+        return json.load(f)
+
+
+REAL_PAIRS = _real_pairs()          # every picture pair the reference holds in testdata/, with the pinned digests
+REAL_CASES = [(k, bd) for k in sorted(REAL_PAIRS) for bd in sorted(REAL_PAIRS[k]["maps"], key=lambda s: tuple(map(int, s.split("/"))))]

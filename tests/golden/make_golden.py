@@ -23,6 +23,15 @@ What it writes (all of it DATA: inputs and expected outputs, no reference source
                                      run on the 4 patches and on small seeded synthetic inputs
   L_00001.png / R_00001.png
       testdata/L_00001.png, R_00001.png copied verbatim (BASELINE config 1 input pair).
+  {L,R}_{00002,00335,01000}.png, im0.png, im1.png, im0-bs.png, im1-bs.png
+      every other picture pair the reference holds in testdata/ (three more 640x480 RGBA pairs, two 1920x1080 RGB
+      pairs), copied verbatim: real content -- exact ties, zero SADs, saturated regions -- for the GPU parity tests.
+  real_pairs.json
+      per pair and (BlockSize, MaxDisparity): sha256 of the gray planes (Go formula: NRGBA for the 640x480 pairs,
+      color.GrayModel on opaque RGB for im0/im1 = what pkg/camera/output.go:145 yields) and of the complete
+      disparity map of the LITERAL restatement (oracle.disparity_rows_mt), plus zero counts; the restatement and the
+      closed form are asserted equal on each before anything is written.  tests/test_oracle_golden.py re-derives
+      them on the CPU, tests/test_parity_gpu.py holds the HIP path to them.
 """
 import hashlib
 import importlib.util
@@ -42,6 +51,50 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 def read_mem(path, width=1):
     vals = [int(t, 16) for t in open(path).read().split()]
     return np.array(vals, dtype=np.uint8 if width == 1 else np.uint32)
+
+
+REAL_640 = ("00001", "00002", "00335", "01000")                 # testdata/{L,R}_<k>.png, 640x480 RGBA
+REAL_1080 = (("im0.png", "im1.png"), ("im0-bs.png", "im1-bs.png"))   # 1920x1080 RGB
+PARAMS_640 = ((7, 32), (9, 64), (16, 64))
+PARAMS_1080 = ((9, 64), (16, 64), (15, 128))
+
+
+def load_gray(path):
+    """What the reference's callers feed the path: Go decodes 8-bit RGBA files as *image.NRGBA and opaque RGB files
+    as *image.RGBA; color.GrayModel.Convert (pkg/camera/output.go:145,160; pkg/despair/gray.go:43-58) on them."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle
+    im = Image.open(path)
+    a = np.array(im)
+    if im.mode == "RGBA":
+        return oracle.gray_from_nrgba(a)
+    assert im.mode == "RGB"
+    return oracle.gray_from_rgb8(a)
+
+
+def write_real_pairs():
+    import json
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle
+    thr = os.cpu_count() or 1
+    rec = {}
+    pairs = [(f"L_{k}.png", f"R_{k}.png", PARAMS_640) for k in REAL_640] + [(a, b, PARAMS_1080) for a, b in REAL_1080]
+    for ln, rn, params in pairs:
+        L, R = load_gray(os.path.join(HERE, ln)), load_gray(os.path.join(HERE, rn))
+        e = {"left": ln, "right": rn, "w": int(L.shape[1]), "h": int(L.shape[0]),
+             "gray_left_sha256": hashlib.sha256(L.tobytes()).hexdigest(),
+             "gray_right_sha256": hashlib.sha256(R.tobytes()).hexdigest(), "maps": {}}
+        for b, d in params:
+            m = oracle.disparity_rows_mt(L, R, b, d, 0, L.shape[0], thr)
+            assert np.array_equal(m, oracle.disparity_closed(L, R, b, d)), (ln, b, d)
+            e["maps"][f"{b}/{d}"] = {"sha256": hashlib.sha256(m.tobytes()).hexdigest(), "zeros": int((m == 0).sum()),
+                                     "distinct": int(len(np.unique(m)))}
+            print(ln, b, d, e["maps"][f"{b}/{d}"])
+        rec[ln] = e
+    with open(os.path.join(HERE, "real_pairs.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+        f.write("\n")
 
 
 def main():
@@ -102,10 +155,12 @@ def main():
     ro["testpy_ncases"] = np.array([len(cases)], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, "reference_outputs.npz"), **ro)
 
-    for n in ("L_00001.png", "R_00001.png"):
+    names = [f"{s}_{k}.png" for k in REAL_640 for s in "LR"] + [n for pair in REAL_1080 for n in pair]
+    for n in names:
         shutil.copy(f"{REF}/testdata/{n}", os.path.join(HERE, n))
         os.chmod(os.path.join(HERE, n), 0o644)
         print(n, hashlib.sha256(open(os.path.join(HERE, n), "rb").read()).hexdigest())
+    write_real_pairs()
     print("golden fixtures written to", HERE)
 
 

@@ -2,11 +2,13 @@
 the reference's own fixtures, outputs of the reference's own C and Python run in the build
 container, the survey digests, and literal == closed form.  No GPU."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
 import oracle
+from conftest import REAL_PAIRS, load_real_gray
 
 # region where Go / sad.c / test.py semantics coincide (SURVEY.md section 8a, last paragraph)
 WIN, D = 15, 64
@@ -121,6 +123,33 @@ def test_survey_digests_real_pair(testdata_pair):
     assert np.array_equal(d, oracle.disparity_closed(L, R, 7, 32))
     d2 = oracle.disparity_closed(L, R, 9, 64)
     assert hashlib.sha256(d2.tobytes()).hexdigest() == "0bde916590100d42d2fb6c0aca7081ba4f912c2b03a8f3bb5a8d9946454317fb"
+
+
+@pytest.mark.parametrize("name", sorted(REAL_PAIRS))
+def test_real_pairs_pinned_digests(name):
+    """Every picture pair of the reference's testdata/ (four 640x480 RGBA pairs, two 1920x1080 RGB pairs): the gray
+    planes and the COMPLETE disparity maps of the literal restatement at the parameters the GPU tests use equal the
+    digests tests/golden/make_golden.py recorded (there: literal == closed form on each).  Real frames carry what the
+    synthetic generator avoids -- exact ties, zero SADs, saturated windows (7 500 .. 130 000 zero pixels per map)."""
+    e = REAL_PAIRS[name]
+    L, R = load_real_gray(e["left"]), load_real_gray(e["right"])
+    assert L.shape == R.shape == (e["h"], e["w"])
+    assert hashlib.sha256(L.tobytes()).hexdigest() == e["gray_left_sha256"]
+    assert hashlib.sha256(R.tobytes()).hexdigest() == e["gray_right_sha256"]
+    for key, m in e["maps"].items():
+        b, d = map(int, key.split("/"))
+        got = oracle.disparity_rows_mt(L, R, b, d, 0, e["h"], os.cpu_count() or 1)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == m["sha256"], (name, key)
+        assert int((got == 0).sum()) == m["zeros"] and len(np.unique(got)) == m["distinct"]
+        hs = b // 2
+        assert not got[:, :hs + 1].any()
+
+
+def test_real_pairs_cover_the_reference_testdata():
+    assert sorted(REAL_PAIRS) == ["L_00001.png", "L_00002.png", "L_00335.png", "L_01000.png", "im0-bs.png", "im0.png"]
+    assert REAL_PAIRS["L_00001.png"]["maps"]["7/32"]["sha256"] == "03a658082e809b4211a1216839d23a7123f1187b56f18dff0b21b6863c8a9d6e"   # SURVEY 8c
+    assert REAL_PAIRS["L_00001.png"]["gray_left_sha256"] == "cf6b08f963bde1f74ca786b8ca787ac036bcf245cbe21e0e055cca225be8a527"
+    assert (REAL_PAIRS["im0.png"]["w"], REAL_PAIRS["im0.png"]["h"]) == (1920, 1080)
 
 
 SHAPES = [  # (w, h, block, maxdisp)

@@ -12,6 +12,7 @@ import pytest
 import oracle
 import steroscopic_hardware_amd as sha
 from steroscopic_hardware_amd import capi
+from conftest import REAL_CASES, REAL_PAIRS, load_real_gray, load_real_pixels
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +56,82 @@ def test_real_pair_default_params_16_64(ctx, testdata_pair):
     L, R = testdata_pair
     assert np.array_equal(sha.despair.RunSad(L, R, 16, 64), _expect(L, R, 16, 64))
     assert (sha.despair.DefaultParams().BlockSize, sha.despair.DefaultParams().MaxDisparity) == (16, 64)
+
+
+# ---- every real picture pair the reference holds (testdata/), complete frames vs the literal restatement ----------
+_REAL_GRAY = {}
+
+
+def _real_gray(name):
+    if name not in _REAL_GRAY:
+        e = REAL_PAIRS[name]
+        _REAL_GRAY[name] = (load_real_gray(e["left"]), load_real_gray(e["right"]))
+    return _REAL_GRAY[name]
+
+
+@pytest.mark.parametrize("name,key", REAL_CASES)
+def test_real_inputs_complete_frames(ctx, name, key):
+    """testdata/{L,R}_{00001,00002,00335,01000}.png (640x480 RGBA) at 7/32, 9/64 and the defaults 16/64; testdata/im0 + im1
+    and im0-bs + im1-bs (1920x1080 RGB -- the headline config's size) at 9/64 (config 3's kernel), 16/64 and 15/128, through
+    the gray formula pkg/camera/output.go:145 applies.  Real frames are where exact ties, zero SADs and saturated windows
+    live (up to 130 000 zero-disparity pixels per map); the synthetic generator avoids them on purpose.  COMPLETE maps:
+    (1) equal to the literal restatement of sad.go:55-94 run here, (2) equal to the digest pinned in the build
+    container (tests/golden/real_pairs.json), (3) the generic kernel agrees, (4) 1080p: the same map as frames 0 and n-1 of
+    a device-resident batch (the batched launch geometry: few tall strips), (5) the fused RGB(A) entry (device gray)."""
+    import torch
+    e = REAL_PAIRS[name]
+    b, d = map(int, key.split("/"))
+    L, R = _real_gray(name)
+    h, w = L.shape
+    exp = oracle.disparity_rows_mt(L, R, b, d, 0, h, min(16, os.cpu_count() or 1))
+    assert hashlib.sha256(exp.tobytes()).hexdigest() == e["maps"][key]["sha256"]
+    got = ctx.disparity(L, R, b, d)
+    assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+    assert np.array_equal(got, exp), (name, key, np.argwhere(got != exp)[:4])
+    assert hashlib.sha256(got.tobytes()).hexdigest() == e["maps"][key]["sha256"]
+    assert int((got == 0).sum()) == e["maps"][key]["zeros"]
+    assert np.array_equal(ctx.disparity(L, R, b, d, capi.FLAG_FORCE_GENERIC), exp)
+    fused = ctx.disparity_rgba(load_real_pixels(e["left"]), load_real_pixels(e["right"]), b, d)
+    assert np.array_equal(fused, exp), (name, key, "fused gray + disparity")
+    # device-resident batch: the real pair first and last, synthetic frames (or the other real pairs) between
+    n = 12 if w == 1920 else 40
+    mid = [sha.synth.synth_pair(4000 + i, w, h) for i in range(3)]
+    Lb = np.stack([L] + [mid[i % 3][0] for i in range(n - 2)] + [L])
+    Rb = np.stack([R] + [mid[i % 3][1] for i in range(n - 2)] + [R])
+    Ls, Rs = torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda()
+    out = torch.full_like(Ls, 0xCD)
+    ctx.disparity_dev(Ls, Rs, out, b, d)
+    torch.cuda.synchronize()
+    assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+    o = out.cpu().numpy()
+    assert np.array_equal(o[0], exp) and np.array_equal(o[n - 1], exp), (name, key, "batched layout")
+    if w == 640:
+        assert np.array_equal(o[1], _expect(mid[0][0], mid[0][1], b, d))
+
+
+def test_real_1080p_pair_raw_ties_and_first_minimum(ctx):
+    """The first-minimum rule (strict <, sad.go:79) on real 1080p content: wherever several candidates tie for the minimum
+    the LOWEST d must come out.  im0/im1 at 9/64, raw d: every pixel against the closed form's raw output on three bands,
+    and the count of pixels whose minimum is attained more than once (from the oracle's SAD table of a band) is > 0 --
+    i.e. the test really exercises ties."""
+    L, R = _real_gray("im0.png")
+    raw = ctx.disparity(L, R, 9, 64, capi.FLAG_RAW)
+    for y0 in (0, 500, 1068):
+        assert np.array_equal(raw[y0:y0 + 12], oracle.disparity_closed(L, R, 9, 64, region=(0, y0, 1920, y0 + 12), raw=True))
+    # ties on one band, counted with plain numpy from full windows (interior columns only)
+    y, hs, D = 540, 4, 64
+    Lf, Rf = L.astype(np.int32), R.astype(np.int32)
+    xs = np.arange(D + hs, 1920 - hs)
+    sads = np.empty((D + 1, len(xs)), np.int64)
+    for dd in range(D + 1):
+        ad = np.abs(Lf[y - hs:y + hs + 1, D:] - Rf[y - hs:y + hs + 1, D - dd:1920 - dd])       # columns D.. of L vs shifted R
+        cs = np.concatenate([np.zeros(1, np.int64), ad.sum(0).cumsum()])
+        sads[dd] = cs[xs - D + hs + 1] - cs[xs - D - hs]
+    best = sads.min(0)
+    ties = (sads == best[None]).sum(0) > 1
+    assert ties.sum() > 0, "no tied minima on this band: pick another"
+    assert np.array_equal(raw[y, xs], sads.argmin(0))                 # argmin = first minimum = lowest d
+    assert (raw[y, xs][ties] == sads.argmin(0)[ties]).all()
 
 
 # ---- hardware fixtures through the GPU (raw d) -------------------------------------------------

@@ -1,34 +1,94 @@
-// dpp_sub.hip -- what v_sub_u32_dpp / v_subrev_u32_dpp with wave_shr:1 compute on gfx950, per lane, against what
-// the ISA text says (V_SUB_U32: D = S0 - S1, V_SUBREV_U32: D = S1 - S0, DPP applies to S0).  Found in round 3: hipcc
-// folds `base - dpp(x)` into v_subrev_u32_dpp and the column-wave kernel's window sums came out wrong.
+// dpp_sub.hip -- what the DPP forms of the 32-bit subtract instructions compute per lane on gfx950, classified against the
+// four readings one could have of "D = v_sub*_u32_dpp S0, S1 <lane shift>":
+//     A  shift(S0) - S1        B  S1 - shift(S0)        C  S0 - shift(S1)        D  shift(S1) - S0
+// The ISA text says V_SUB_U32: D = S0 - S1, V_SUBREV_U32: D = S1 - S0, DPP selects the lane of S0 -> sub_dpp = A, subrev_dpp = B.
+// Round 3: the column-wave kernel's window sums for BlockSize 16 were wrong on every pixel after hipcc folded
+// `base - dpp(x)` (v_mov_b32_dpp + v_sub_u32) into one v_subrev_u32_dpp; this program is the isolated check.  It prints,
+// per instruction form and lane-shift control, how many of the 64 lanes agree with each reading, plus a few raw lanes.
+// The operand ORDER the assembler gives the instruction (which register lands in the src0 field, the one DPP applies to)
+// is a separate question: `make -C tools/ubench dpp_sub.dis` / profiles/ubench_dpp_sub_disasm.txt holds llvm-objdump's view
+// of the very instructions executed here.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-__global__ void k(unsigned* out)
+
+#define DPPK(name, ins, ctrl)                                                                                              \
+  __global__ void name(unsigned* out)                                                                                     \
+  {                                                                                                                       \
+    const unsigned lane = threadIdx.x;                                                                                    \
+    unsigned a = 1000u * lane + 7u, b = 5000000u + 3u * lane, r;                                                          \
+    asm volatile("s_nop 4\n\t" ins " %0, %1, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 4" : "=v"(r) : "v"(a), "v"(b)); \
+    out[lane] = r;                                                                                                        \
+  }
+// first asm operand after the destination = a ("S0" as written), second = b ("S1" as written)
+DPPK(k_sub_wshr, "v_sub_u32_dpp", "wave_shr:1")
+DPPK(k_subrev_wshr, "v_subrev_u32_dpp", "wave_shr:1")
+DPPK(k_sub_rshr, "v_sub_u32_dpp", "row_shr:1")
+DPPK(k_subrev_rshr, "v_subrev_u32_dpp", "row_shr:1")
+DPPK(k_add_wshr, "v_add_u32_dpp", "wave_shr:1")
+DPPK(k_sub_wshl, "v_sub_u32_dpp", "wave_shl:1")
+DPPK(k_subrev_wshl, "v_subrev_u32_dpp", "wave_shl:1")
+
+// what the compiler makes of `b - dpp(a)` and `dpp(a) - b` written with the builtin (the fold that went wrong)
+__global__ void k_builtin(unsigned* out)
 {
   const unsigned lane = threadIdx.x;
-  unsigned x = 1000u * lane + 7u, base = 5000000u + lane;
-  unsigned r_subrev, r_sub, r_mov, r_add;
-  asm volatile("s_nop 4\n\tv_subrev_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r_subrev) : "v"(x), "v"(base));
-  asm volatile("s_nop 4\n\tv_sub_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r_sub) : "v"(x), "v"(base));
-  asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r_mov) : "v"(x));
-  asm volatile("s_nop 4\n\tv_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r_add) : "v"(x), "v"(base));
-  out[lane * 4 + 0] = r_subrev; out[lane * 4 + 1] = r_sub; out[lane * 4 + 2] = r_mov; out[lane * 4 + 3] = r_add;
+  unsigned a = 1000u * lane + 7u, b = 5000000u + 3u * lane;
+  const unsigned sa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+  out[lane] = b - sa;
+  out[64 + lane] = sa - b;
 }
+
+static unsigned A_(unsigned l) { return 1000u * l + 7u; }
+static unsigned B_(unsigned l) { return 5000000u + 3u * l; }
+
+// src lane of destination lane l under the control, or -1 (bound_ctrl:1 -> the operand reads 0)
+static int src_lane(const char* ctrl, int l)
+{
+  if (ctrl[0] == 'w' && ctrl[7] == 'r') return l - 1;                              // wave_shr:1
+  if (ctrl[0] == 'w') return l + 1 < 64 ? l + 1 : -1;                              // wave_shl:1
+  return (l % 16) ? l - 1 : -1;                                                    // row_shr:1
+}
+
+static void classify(const char* name, const char* ctrl, const unsigned* h, bool add)
+{
+  int nA = 0, nB = 0, nC = 0, nD = 0;
+  for (int l = 0; l < 64; ++l) {
+    const int s = src_lane(ctrl, l);
+    const unsigned sa = s < 0 ? 0u : A_(s), sb = s < 0 ? 0u : B_(s), a = A_(l), b = B_(l);
+    if (add) { nA += h[l] == sa + b; nC += h[l] == a + sb; continue; }
+    nA += h[l] == sa - b; nB += h[l] == b - sa; nC += h[l] == a - sb; nD += h[l] == sb - a;
+  }
+  if (add) printf("%-28s %-10s lanes equal to  shift(S0)+S1: %2d   S0+shift(S1): %2d\n", name, ctrl, nA, nC);
+  else printf("%-28s %-10s lanes equal to  A shift(S0)-S1: %2d   B S1-shift(S0): %2d   C S0-shift(S1): %2d   D shift(S1)-S0: %2d\n", name, ctrl, nA, nB, nC, nD);
+  printf("    raw lanes 0,1,2,16,17,63: %u %u %u %u %u %u\n", h[0], h[1], h[2], h[16], h[17], h[63]);
+}
+
+#define RUN(kern, name, ctrl, add)                                                             \
+  do {                                                                                         \
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, 0, d);                                      \
+    if (hipMemcpy(h, d, 64 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return 1; \
+    classify(name, ctrl, h, add);                                                              \
+  } while (0)
+
 int main()
 {
-  unsigned* d; unsigned h[256];
+  unsigned* d; unsigned h[128];
   if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return 1;
-  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
+  printf("operands as written in the asm: S0 = a = 1000*lane+7, S1 = b = 5000000+3*lane; bound_ctrl:1 (a lane without source reads 0)\n");
+  RUN(k_sub_wshr, "v_sub_u32_dpp D, a, b", "wave_shr:1", false);
+  RUN(k_subrev_wshr, "v_subrev_u32_dpp D, a, b", "wave_shr:1", false);
+  RUN(k_sub_rshr, "v_sub_u32_dpp D, a, b", "row_shr:1", false);
+  RUN(k_subrev_rshr, "v_subrev_u32_dpp D, a, b", "row_shr:1", false);
+  RUN(k_sub_wshl, "v_sub_u32_dpp D, a, b", "wave_shl:1", false);
+  RUN(k_subrev_wshl, "v_subrev_u32_dpp D, a, b", "wave_shl:1", false);
+  RUN(k_add_wshr, "v_add_u32_dpp D, a, b", "wave_shr:1", true);
+  hipLaunchKernelGGL(k_builtin, dim3(1), dim3(64), 0, 0, d);
   if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-  int bad_subrev = 0, bad_sub = 0, bad_add = 0;
-  for (unsigned l = 0; l < 64; ++l) {
-    const unsigned xl = l ? 1000u * (l - 1) + 7u : 0u, base = 5000000u + l;      // dpp(x): lane l-1's x, lane 0: 0
-    if (h[l * 4 + 2] != xl) printf("mov lane %u: %u expected %u\n", l, h[l * 4 + 2], xl);
-    bad_subrev += h[l * 4 + 0] != base - xl; bad_sub += h[l * 4 + 1] != xl - base; bad_add += h[l * 4 + 3] != xl + base;
+  int ok1 = 0, ok2 = 0;
+  for (int l = 0; l < 64; ++l) {
+    const unsigned sa = l ? A_(l - 1) : 0u;
+    ok1 += h[l] == B_(l) - sa; ok2 += h[64 + l] == sa - B_(l);
   }
-  for (unsigned l : {0u, 1u, 2u, 15u, 16u, 17u, 63u})
-    printf("lane %2u: subrev_dpp %10u (S1-dpp(S0) = %10u, dpp(S0)-S1 = %10u)   sub_dpp %10u   mov_dpp %u   add_dpp %u\n", l, h[l * 4], 5000000u + l - (l ? 1000u * (l - 1) + 7u : 0u),
-           (l ? 1000u * (l - 1) + 7u : 0u) - (5000000u + l), h[l * 4 + 1], h[l * 4 + 2], h[l * 4 + 3]);
-  printf("lanes where v_subrev_u32_dpp != S1 - dpp(S0): %d; v_sub_u32_dpp != dpp(S0) - S1: %d; v_add_u32_dpp wrong: %d\n", bad_subrev, bad_sub, bad_add);
+  printf("compiler, C source `b - update_dpp(a, wave_shr:1)`: %2d of 64 lanes right;  `update_dpp(a) - b`: %2d of 64 right\n", ok1, ok2);
   return 0;
 }
