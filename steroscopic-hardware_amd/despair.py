@@ -180,11 +180,37 @@ def RunSad(left, right, blockSize, maxDisparity):
     size (sad.go:131,168); a right image of another size is handled as the reference's loops do
     (sadhip_disparity_lr_u8: sad.go:212-218,225-227,231-233), never read past its end."""
     SetDefaultParams(Parameters(BlockSize=blockSize, MaxDisparity=maxDisparity))
+    return RunSadFrame(left, right, Parameters(BlockSize=blockSize, MaxDisparity=maxDisparity))
+
+
+def RunSadFrame(left, right, p):
+    """The Go shim's RunSadFrame (host/go/sad_hip.go): RunSad WITHOUT the write to the process-wide parameters --
+    what a frame loop calls that only reads them (pkg/camera/output.go:169)."""
     h, w = left.shape
     with _context(w, h) as c:
         if right.shape != left.shape:
-            return c.disparity_lr(left, right, blockSize, maxDisparity)
-        return c.disparity(left, right, blockSize, maxDisparity)
+            return c.disparity_lr(left, right, p.BlockSize, p.MaxDisparity)
+        return c.disparity(left, right, p.BlockSize, p.MaxDisparity)
+
+
+def RunSadImages(left_pix, right_pix, p):
+    """The Go shim's RunSadImages: two DECODED pictures in (HxW uint8 = *image.Gray, HxWx4 = *image.NRGBA, HxWx3 =
+    opaque RGB, which Go holds as *image.RGBA with alpha 255), disparity map out, without the per-pixel
+    color.GrayModel.Convert loops of pkg/camera/output.go:142-147,157-162 on the host (patches/0003): two colour
+    pictures of one size and channel count are ONE sadhip_disparity_rgba_u8 call (gray on the device); gray pictures
+    go as they are; pictures of different sizes or channel counts are converted one by one (sadhip_gray_u8) and sent
+    through the lr entry, each with its own size.  Only READS p."""
+    if left_pix.ndim == 3 and right_pix.ndim == 3 and left_pix.shape == right_pix.shape:
+        h, w = left_pix.shape[:2]
+        with _context(w, h) as c:
+            return c.disparity_rgba(left_pix, right_pix, p.BlockSize, p.MaxDisparity)
+
+    def gray_of(pix):
+        if pix.ndim == 2:
+            return pix
+        with _context(pix.shape[1], pix.shape[0]) as c:
+            return c.gray(pix)
+    return RunSadFrame(gray_of(left_pix), gray_of(right_pix), p)
 
 
 def RunSadPixels(left_pix, right_pix, blockSize, maxDisparity):

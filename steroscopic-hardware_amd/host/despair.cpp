@@ -144,6 +144,12 @@ Gray AssembleDisparityMap(Chan<OutputChunk>& out, Rectangle dimensions, int chun
 Gray RunSad(const Gray& left, const Gray& right, int blockSize, int maxDisparity, int device)
 {
   SetDefaultParams(Parameters{blockSize, maxDisparity});                                // sad.go:123-126
+  return RunSadFrame(left, right, Parameters{blockSize, maxDisparity}, device);
+}
+
+Gray RunSadFrame(const Gray& left, const Gray& right, Parameters p, int device)
+{
+  const int blockSize = p.BlockSize, maxDisparity = p.MaxDisparity;
   Gray out(left.Rect);                                                                  // sad.go:135,168: the LEFT image's rectangle
   Lease ctx(dev_or_default(device), left.Rect.Dx(), left.Rect.Dy());
   if (right.Rect.Dx() == left.Rect.Dx() && right.Rect.Dy() == left.Rect.Dy())
@@ -227,9 +233,18 @@ Gray LoadPNG(const std::string& filename, LoadPNGOptions opt) { return ToGray(Lo
 
 Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDisparity, int device, int* uploads_out)
 {
-  // pictures of different sizes (left.png / right.png are uploaded independently): gray planes + the lr entry below
+  SetDefaultParams(Parameters{blockSize, maxDisparity});                                // sad.go:123-126
+  return RunSadImages(left, right, Parameters{blockSize, maxDisparity}, device, uploads_out);
+}
+
+Gray RunSadImages(const Picture& left, const Picture& right, Parameters p, int device, int* uploads_out)
+{
+  const int blockSize = p.BlockSize, maxDisparity = p.MaxDisparity;
+  // the Go shim's RunSadImages (host/go/sad_hip.go): two 8-bit RGB(A) pictures of one size and channel count are ONE
+  // device call; gray pictures go as they are; anything else -- other pixel formats, pictures of different sizes or
+  // channel counts (left.png / right.png are uploaded independently) -- is converted per picture (ToGray = GrayOf) and
+  // sent through the lr entry, each picture with its own size
   if (left.w == right.w && left.h == right.h && left.device_gray_ok() && right.device_gray_ok() && left.channels == right.channels) {
-    SetDefaultParams(Parameters{blockSize, maxDisparity});                              // sad.go:123-126
     Gray out(left.w, left.h);
     Lease ctx(dev_or_default(device), left.w, left.h);
     check(sadhip_disparity_rgba_u8(ctx.get(), left.samples.data(), right.samples.data(), left.channels, left.w, left.h,
@@ -245,7 +260,7 @@ Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDis
   if (left.device_gray_ok() || (GoImage)left.kind == GoImage::Paletted) ++up;
   if (right.device_gray_ok() || (GoImage)right.kind == GoImage::Paletted) ++up;
   if (uploads_out) *uploads_out = up;
-  return RunSad(ToGray(left, opt), ToGray(right, opt), blockSize, maxDisparity, device);
+  return RunSadFrame(ToGray(left, opt), ToGray(right, opt), p, device);
 }
 
 void SavePNG(const std::string& filename, const Gray& img)

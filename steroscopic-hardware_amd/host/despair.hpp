@@ -109,6 +109,9 @@ Pipeline SetupConcurrentSAD(int numWorkers, int device = -1);
 Gray AssembleDisparityMap(Chan<OutputChunk>& out, Rectangle dimensions, int chunks);
 // sad.go:119-169: sets the global parameters, one frame-level device call.
 Gray RunSad(const Gray& left, const Gray& right, int blockSize, int maxDisparity, int device = -1);
+// The Go shim's RunSadFrame (host/go/sad_hip.go): RunSad WITHOUT the write to the process-wide parameters -- what a frame
+// loop calls that only reads them (pkg/camera/output.go:169).  left and right travel with their own sizes.
+Gray RunSadFrame(const Gray& left, const Gray& right, Parameters p, int device = -1);
 // png.go:10-41: decode, then the reference's type switch -- *image.Gray is copied, everything else
 // goes through the Go luminance formula on alpha-premultiplied 16-bit channels (gray.go:43-58),
 // computed on the device for 8-bit RGB/NRGBA (sadhip_gray_u8).  Throws Error(SADHIP_ERR_ARG, ..)
@@ -136,6 +139,10 @@ Gray ToGray(const Picture& p, LoadPNGOptions opt = {});             // the type 
 // sadhip_disparity_rgba_u8 call (uploads: one per image; the gray planes exist only in HBM).
 // Anything else: ToGray + RunSad.  uploads_out (optional): number of host-to-device image uploads made.
 Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDisparity, int device = -1, int* uploads_out = nullptr);
+// The Go shim's RunSadImages: the same without the write to the process-wide parameters -- what patches/0003 makes
+// OutputCamera.processDepthMap call on the two decoded pictures instead of its color.GrayModel.Convert loops
+// (pkg/camera/output.go:142-147,157-162).
+Gray RunSadImages(const Picture& left, const Picture& right, Parameters p, int device = -1, int* uploads_out = nullptr);
 // device / wall time of the last RunSad of the calling thread ("elapsed" of output.go:200-204)
 void LastTiming(float* kernel_ms, float* total_ms);
 

@@ -22,10 +22,18 @@ func RunSad(left, right *image.Gray, blockSize, maxDisparity int) *image.Gray {
 	return runSadGo(left, right, blockSize, maxDisparity)
 }
 
-// RunSadFrame exists so that pkg/camera compiles in both builds (patch 0002); with FrameLevel == false it is
-// never called.  In the hip build it is RunSad without the write to the process-wide parameters.
+// RunSadFrame is RunSad WITHOUT the write to the process-wide parameters (the hip build: one device call;
+// here: the reference's workers with p, runSadFrameGo).  pkg/camera compiles against it in both builds
+// (patch 0002); with FrameLevel == false OutputCamera keeps its chunk pipeline and never calls it.
 func RunSadFrame(left, right *image.Gray, p Parameters) *image.Gray {
-	return runSadGo(left, right, p.BlockSize, p.MaxDisparity)
+	return runSadFrameGo(left, right, p)
+}
+
+// RunSadImages is what pkg/camera/output.go:142-190 does with two decoded pictures -- the gray conversion of
+// both (GrayOf), then the disparity map -- with the parameters p (patch 0003; the hip build converts on the
+// device).  With FrameLevel == false OutputCamera never calls it.
+func RunSadImages(left, right image.Image, p Parameters) *image.Gray {
+	return runSadFrameGo(GrayOf(left), GrayOf(right), p)
 }
 
 // NewPinnedGray is image.NewGray in this build (the hip build returns page-locked memory); free is a no-op.

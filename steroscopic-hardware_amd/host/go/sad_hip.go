@@ -11,7 +11,8 @@
 //
 // Device: environment variable SADHIP_DEVICE (HIP ordinal, default 0), read once.
 // Fallback: any non-zero status logs a warning and runs the reference's own Go loop (the
-// unexported functions of sad.go) -- there is no second copy of that loop here.
+// unexported functions of sad.go) -- there is no second copy of that loop here.  A frame-level call
+// (RunSadFrame, RunSadImages) falls back with the parameters it was given (runSadFrameGo, sad_frame.go).
 //
 // NOTE: the build container has no Go toolchain (`go: command not found`), so this file is not
 // compiled by the repository's tests; the identical logic is exercised through the C++ mirror
@@ -136,7 +137,8 @@ func regionHIP(left, right *image.Gray, p Parameters, r image.Rectangle) ([]uint
 }
 
 // goFallback is a lazily started instance of the reference's own worker pool (sad.go:29-113),
-// used for chunks the device refused.
+// used for chunks of the channel API the device refused: like every chunk of that API it runs with the
+// process-wide parameters, snapshotted by the worker itself (sad.go:51-53).
 var goFallback struct {
 	once sync.Once
 	mu   sync.Mutex
@@ -200,13 +202,78 @@ func RunSadFrame(left, right *image.Gray, p Parameters) *image.Gray {
 		return out
 	}
 	slog.Warn("HIP disparity failed, using the Go path", "err", err)
-	// the reference's worker on the whole frame as one chunk; it snapshots the process-wide parameters per
-	// chunk itself (sad.go:51-53) and writes nothing back
-	chunk := regionGo(InputChunk{Left: left, Right: right, Region: left.Rect})
-	for y := 0; y < left.Rect.Dy(); y++ {
-		copy(out.Pix[y*out.Stride:y*out.Stride+left.Rect.Dx()], chunk.DisparityData[y*left.Rect.Dx():(y+1)*left.Rect.Dx()])
+	// the reference's own workers with the parameters of THIS call (runSadFrameGo, sad_frame.go): the fallback
+	// computes what the device would have, whatever the process-wide parameters are by now
+	return runSadFrameGo(left, right, p)
+}
+
+// rgba8 reports whether img's pixels can go to sadhip_disparity_rgba_u8 as they are: 8-bit, four interleaved
+// channels, NON-premultiplied alpha -- *image.NRGBA (what png.Decode returns for colour type 6), or *image.RGBA
+// whose alpha is 255 everywhere (colour type 2; premultiplied == non-premultiplied there).  pix starts at
+// Rect.Min.
+func rgba8(img image.Image) (pix []uint8, stride int, ok bool) {
+	switch m := img.(type) {
+	case *image.NRGBA:
+		if m.Rect.Empty() {
+			return nil, 0, false
+		}
+		return m.Pix[m.PixOffset(m.Rect.Min.X, m.Rect.Min.Y):], m.Stride, true
+	case *image.RGBA:
+		if m.Rect.Empty() || !m.Opaque() {
+			return nil, 0, false
+		}
+		return m.Pix[m.PixOffset(m.Rect.Min.X, m.Rect.Min.Y):], m.Stride, true
 	}
-	return out
+	return nil, 0, false
+}
+
+// imagesHIP is one sadhip_disparity_rgba_u8 call: one upload per picture (2-D copies from the pictures' own rows),
+// the Go luminance -- color.GrayModel on alpha-premultiplied 16-bit channels, bit for bit -- and the disparity
+// search on the device, one download.  No gray plane exists on the host.
+func imagesHIP(lpix []uint8, lstride int, rpix []uint8, rstride int, w, h int, p Parameters) (*image.Gray, error) {
+	out := image.NewGray(image.Rect(0, 0, w, h))
+	err := ctx.with(w, h, func(c *C.sadhip_ctx) error {
+		st := C.sadhip_disparity_rgba_u8(c,
+			(*C.uint8_t)(unsafe.Pointer(&lpix[0])), (*C.uint8_t)(unsafe.Pointer(&rpix[0])), 4,
+			C.int(w), C.int(h), C.int(lstride), C.int(rstride),
+			C.int(p.BlockSize), C.int(p.MaxDisparity), 0,
+			(*C.uint8_t)(unsafe.Pointer(&out.Pix[0])), C.int(out.Stride))
+		runtime.KeepAlive(lpix)
+		runtime.KeepAlive(rpix)
+		if st != C.SADHIP_OK {
+			return statusErr("sadhip_disparity_rgba_u8", st)
+		}
+		return nil
+	})
+	return out, err
+}
+
+// RunSadImages computes the disparity map of two DECODED pictures -- what png.Decode hands
+// OutputCamera.processDepthMap (pkg/camera/output.go:138,153; patches/0003) -- without the two per-pixel
+// color.GrayModel.Convert loops of output.go:142-147,157-162 on the host:
+//
+//	*image.NRGBA, or *image.RGBA with alpha 255 everywhere, both of one size  one sadhip_disparity_rgba_u8 call
+//	                                                                          (gray conversion on the device)
+//	*image.Gray (what StaticCamera saves as left.png / right.png,            RunSadFrame on the pictures' own
+//	             pkg/camera/static.go:141)                                    pixels: the conversion is the identity
+//	anything else (16-bit, paletted, premultiplied alpha < 255), or          GrayOf on the host (the reference's
+//	pictures of different sizes                                               loop), then RunSadFrame, which sends
+//	                                                                          each picture with its own size
+//
+// Like RunSadFrame it only READS p: nothing is written to the process-wide parameters.  The result's rectangle
+// is the left picture's, moved to the origin (sad.go:135,168 on a gray image made by image.NewGray(Bounds())).
+func RunSadImages(left, right image.Image, p Parameters) *image.Gray {
+	lb, rb := left.Bounds(), right.Bounds()
+	if lpix, ls, ok := rgba8(left); ok && lb.Size() == rb.Size() {
+		if rpix, rs, ok := rgba8(right); ok {
+			out, err := imagesHIP(lpix, ls, rpix, rs, lb.Dx(), lb.Dy(), p)
+			if err == nil {
+				return out
+			}
+			slog.Warn("HIP disparity on decoded pictures failed, converting on the host", "err", err)
+		}
+	}
+	return RunSadFrame(GrayOf(left), GrayOf(right), p)
 }
 
 // NewPinnedGray returns an *image.Gray whose Pix lives in page-locked memory from sadhip_host_alloc (C memory,

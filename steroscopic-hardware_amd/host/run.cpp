@@ -1,6 +1,6 @@
 // run.cpp -- counterpart of the reference's examples/run.go: load the stereo pair, RunSad with the
 // default parameters of that example (16, 64), save the disparity map.
-//   usage: run [left.png right.png [out.png [block maxdisp]]]
+//   usage: run [left.png right.png [out.png [block maxdisp]]] [--frame]
 // The decoded pictures stay in memory between decode, disparity and SavePNG: an
 // RGB(A) pair is uploaded once per image and converted to gray on the device
 // (sadhip_disparity_rgba_u8) -- no host gray plane, no $HOME/*.png round trip.  The timing line
@@ -9,9 +9,12 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 int main(int argc, char** argv)
 {
+  bool frame_mode = false;
+  if (argc > 1 && std::string(argv[argc - 1]) == "--frame") { frame_mode = true; --argc; }
   const char* left = argc > 2 ? argv[1] : "./testdata/L_00001.png";     // run.go:21
   const char* right = argc > 2 ? argv[2] : "./testdata/R_00001.png";    // run.go:26
   const char* out = argc > 3 ? argv[3] : "output.png";                  // run.go:31
@@ -22,7 +25,15 @@ int main(int argc, char** argv)
     const despair::Picture L = despair::LoadPicture(left), R = despair::LoadPicture(right);
     const auto t1 = clk::now();
     int uploads = 0;
-    const despair::Gray got = despair::RunSad(L, R, block, maxdisp, -1, &uploads);
+    // --frame: what patches/0003 makes OutputCamera call per frame -- RunSadImages with the parameters READ from the
+    // process-wide ones (written here first, as POST /update-params would), nothing written back
+    despair::Gray got;
+    if (frame_mode) {
+      despair::SetDefaultParams(despair::Parameters{block, maxdisp});
+      got = despair::RunSadImages(L, R, despair::DefaultParams(), -1, &uploads);
+    } else {
+      got = despair::RunSad(L, R, block, maxdisp, -1, &uploads);
+    }
     const auto t2 = clk::now();
     float kernel_ms = 0.f, call_ms = 0.f;
     despair::LastTiming(&kernel_ms, &call_ms);
