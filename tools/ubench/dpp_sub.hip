@@ -16,7 +16,7 @@
   {                                                                                                                       \
     const unsigned lane = threadIdx.x;                                                                                    \
     unsigned a = 1000u * lane + 7u, b = 5000000u + 3u * lane, r;                                                          \
-    asm volatile("s_nop 4\n\t" ins " %0, %1, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 4" : "=v"(r) : "v"(a), "v"(b)); \
+    asm volatile("s_nop 4\n\t" ins " %0, %1, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 4" : "=&v"(r) : "v"(a), "v"(b)); \
     out[lane] = r;                                                                                                        \
   }
 // first asm operand after the destination = a ("S0" as written), second = b ("S1" as written)
