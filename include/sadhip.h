@@ -226,7 +226,8 @@ SADHIP_API int sadhip_last_kernel_kind(void);
 
 /* How the fast kernel would run a parameter set (diagnostics / tests; needs no GPU): writes one
  * line per pass, "dbase=<first candidate> count=<candidates> p=<columns per lane> nd=<chunk> nw=<waves>
- * packed=<0|1> extra=<0|1> w16=<0|1> lds=<bytes>", into buf (NUL-terminated, truncated to cap).
+ * packed=<0|1> extra=<0|1> w16=<0|1> nwh=<trailing waves with chunks of nd/2: mixed-chunk plans, else 0> lds=<bytes>", into buf
+ * (NUL-terminated, truncated to cap).
  * Returns the number of passes, 0 when the generic kernel would run, -1 on invalid parameters. */
 SADHIP_API int sadhip_plan_describe(int w, int h, int block, int maxdisp, char* buf, int cap);
 

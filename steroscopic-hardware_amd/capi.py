@@ -162,7 +162,7 @@ def last_kernel_kind():
 
 def plan_describe(w, h, block, maxdisp):
     """The passes the column-wave kernel would run (no GPU needed): list of dicts with the integer
-    fields dbase, count, p, nd, nw, packed, extra, w16, lds; [] when the generic kernel would run."""
+    fields dbase, count, p, nd, nw, packed, extra, w16, nwh, lds; [] when the generic kernel would run."""
     buf = C.create_string_buffer(16384)
     n = lib().sadhip_plan_describe(w, h, block, maxdisp, buf, len(buf))
     if n < 0:

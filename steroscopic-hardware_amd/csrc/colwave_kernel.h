@@ -57,7 +57,9 @@ namespace {
 struct CwArgs {
   Job j;
   int nw;          // waves per workgroup (disparity chunks), 4..16
-  int xw;          // wave that also owns candidate nw*ND (the 16k+1-th), or -1
+  int nwa;         // waves [0, nwa) own ND candidates each; mixed-chunk kernels (k_colwave<..., MIX>): waves [nwa, nw) own ND/2 each.  nwa == nw otherwise
+  int slots;       // candidates of the pass without the odd one: nwa*ND + (nw - nwa)*ND/2
+  int xw;          // wave that also owns candidate `slots` (the 16k+1-th), or -1
   int ksh;         // bits of the disparity field of a key (unpacked: 2^ksh > maxdisp; packed: 16)
   int pixshift;    // left shift applied to pixels landing in LDS (unpacked: ksh; packed: 0)
   int dpad;        // columns of R kept left of the tile (== 3 mod 4, >= largest candidate)
@@ -246,7 +248,12 @@ struct Cw {                                         // P columns per lane: 4 (pa
   // W16: ring pixels are u16 (two per dword) instead of u32 -- half the LDS per workgroup, one
   // v_and / v_lshrrev more per operand.  For the variants whose ring (2h+4 rows of 1100 pixels)
   // otherwise leaves room for one workgroup per CU: P = 8, h >= 7.
-  static_assert(!W16 || (P == 8 && ND == 8), "u16 ring: whole 16-byte reads need P and ND multiples of 8");
+  // ND = 8: every operand block is whole 16-byte reads.  ND = 4 (round 4; 16k+1 candidates with k odd -- D = 16, 48, 80, ... --
+  // plan as 4-candidate chunks instead of rounding up to 8): a lane's 12 R pixels are 24 bytes that start on an 8-byte
+  // boundary (on a 16-byte one for every other wave), read as three ds_read_b64; ring rows stay 16-byte multiples for
+  // even wave counts (plan_count_p / launch_t check).
+  static_assert(!W16 || (P == 8 && (ND == 8 || ND == 4)), "u16 ring: P = 8, chunks of 8 (16-byte reads) or 4 (8-byte reads of the R operands)");
+  static constexpr bool R_A16 = !W16 || ND % 8 == 0;   // a lane's R operand block starts 16-byte aligned
   using Px = typename std::conditional<W16, unsigned short, unsigned>::type;
   // SWZ: quad-swizzled ring rows for the u32 ring of the P = 8, ND = 8 variants.  A lane's operands
   // are 8 (L) / 16 (R) consecutive pixels = 32-byte lane stride: as ds_read_b128 that is a 2-way bank
@@ -311,21 +318,31 @@ struct Cw {                                         // P columns per lane: 4 (pa
   };
 
   // N ring pixels starting at a 16-byte aligned element -> one u32 register each.
-  template <int N>
+  // (u16 ring, A16 = false: N ring pixels starting at an 8-byte aligned element, ds_read_b64 each)
+  template <int N, bool A16 = true>
   static __device__ __forceinline__ void load_px(Src src, unsigned (&out)[N])
   {
     const uint4* s4 = reinterpret_cast<const uint4*>(src.a);
     if constexpr (W16) {
-      static_assert(N % 8 == 0, "");
       // the mask lives in a VGPR: v_and_b32 with the 32-bit literal 0xffff is a slow-class instruction
       // (4.2 cycles), with a register operand it is fast-class (2.3 in a run) -- tools/ubench/valu_rates.hip
       unsigned lo16 = 0xffffu;
       asm("" : "+v"(lo16));
+      if constexpr (A16 && N % 8 == 0) {
 #pragma unroll
-      for (int m = 0; m < N / 8; ++m) {
-        const uint4 v = s4[m];
-        out[8 * m] = v.x & lo16; out[8 * m + 1] = v.x >> 16; out[8 * m + 2] = v.y & lo16; out[8 * m + 3] = v.y >> 16;
-        out[8 * m + 4] = v.z & lo16; out[8 * m + 5] = v.z >> 16; out[8 * m + 6] = v.w & lo16; out[8 * m + 7] = v.w >> 16;
+        for (int m = 0; m < N / 8; ++m) {
+          const uint4 v = s4[m];
+          out[8 * m] = v.x & lo16; out[8 * m + 1] = v.x >> 16; out[8 * m + 2] = v.y & lo16; out[8 * m + 3] = v.y >> 16;
+          out[8 * m + 4] = v.z & lo16; out[8 * m + 5] = v.z >> 16; out[8 * m + 6] = v.w & lo16; out[8 * m + 7] = v.w >> 16;
+        }
+      } else {
+        static_assert(N % 4 == 0, "");
+        const uint2* s2 = reinterpret_cast<const uint2*>(src.a);
+#pragma unroll
+        for (int m = 0; m < N / 4; ++m) {
+          const uint2 v = s2[m];
+          out[4 * m] = v.x & lo16; out[4 * m + 1] = v.x >> 16; out[4 * m + 2] = v.y & lo16; out[4 * m + 3] = v.y >> 16;
+        }
       }
     } else {
       static_assert(N % 4 == 0, "");
@@ -345,7 +362,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
     {
       unsigned li[P], ri[NRV];
       load_px(lin, li);
-      load_px(rin, ri);
+      load_px<NRV, R_A16>(rin, ri);
       if constexpr (PK) {
 #pragma unroll
         for (int p = 0; p < P; ++p)
@@ -364,7 +381,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
     {
       unsigned lo[P], ro[NRV];
       load_px(lout, lo);
-      load_px(rout, ro);
+      load_px<NRV, R_A16>(rout, ro);
       if constexpr (PK) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -674,7 +691,10 @@ struct Cw {                                         // P columns per lane: 4 (pa
     }
   }
 
-  static __device__ void run(const CwArgs& a)
+  // wv0 / dcl0: first wave of this wave's group and the group's first candidate within the pass (0, 0 unless the kernel
+  // mixes two chunk sizes: there the waves [nwa, nw) run Cw<P, ND/2, ...>::run(a, nwa, nwa*ND) on the SAME ring, row
+  // buffers and barriers -- every quantity of the LDS layout below depends on a.slots / a.nw, none on ND)
+  static __device__ void run(const CwArgs& a, const int wv0 = 0, const int dcl0 = 0)
   {
     extern __shared__ __attribute__((aligned(16))) unsigned smem[];
     const Job& j = a.j;
@@ -682,7 +702,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dcl = wv * ND;                              // first disparity of this wave within the pass
+    const int dcl = dcl0 + (wv - wv0) * ND;               // first disparity of this wave within the pass
     const int dc = a.dbase + dcl;                         // ... and absolute
     const int RW = TW + a.dpad + 1;                       // R values per ring row (16 bytes' worth aligned)
     const int ROWW = TW + RW;                             // pixels per ring row: L[TW] then R[RW]
@@ -892,8 +912,8 @@ struct Cw {                                         // P columns per lane: 4 (pa
     // ---- per-lane state ------------------------------------------------------------------------
     const int x0 = tx + P * lane;                         // first column of this lane
     const bool lane_valid = x0 < j.w;                     // (w - tx) % P == 0: all-or-nothing
-    const bool xtra = wv == a.xw;                         // this wave also owns candidate dx = nw*ND
-    const int dx = a.dbase + a.nw * ND;
+    const bool xtra = wv == a.xw;                         // this wave also owns candidate dx = the pass's slot count
+    const int dx = a.dbase + a.slots;
     // Candidates d > x-h do not exist near the left image edge (sad.go:66-69).  Instead of masking
     // their keys in every row (which made the leftmost tile's workgroups the critical path of the
     // whole launch), their column sums start with a penalty that outlives the sliding updates:
@@ -973,7 +993,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
     //  c = (dpad - dcl - (ND-1)) / 4 = 2 * (nw - wv) is even, so even j read half 0 and odd j half 1)
     const int lofs = SWZ ? 4 * lane : P * lane;
     const int rofs = TW + (SWZ ? 4 * (a.nw - wv + lane) : (a.dpad - dcl - (ND - 1)) + P * lane);   // 16-byte aligned by construction (dpad = nw*ND + XOFF)
-    const int rxofs = TW + (SWZ ? 4 * lane : (a.dpad - a.nw * ND - XOFF) + P * lane);             // extra candidate: R value of column p at +XOFF+p
+    const int rxofs = TW + (SWZ ? 4 * lane : (a.dpad - a.slots - XOFF) + P * lane);               // extra candidate: R value of column p at +XOFF+p
     const int lhalf = SWZ ? TW / 2 : 0, rhalf = SWZ ? RW / 2 : 0;
 
     // ---- main loop: step t brings in image row ys-H+t (ring slot t % NR) ------------------------
@@ -1072,10 +1092,22 @@ struct Cw {                                         // P columns per lane: 4 (pa
 // WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
 // TR: the kernel holds both forms of the row loop (Cw::TR3): the triple-column form for the workgroups whose tile does
 // not hold the image's last two columns, the plain form for the others.
-template <int P, int ND, int H, bool PK, int WB, bool W16, bool TR = false>
+// MIX (round 4): a workgroup of nwa waves with ND candidates each followed by nw - nwa waves with ND/2 each, for disparity
+// ranges that are no multiple of ND per SIMD -- 49 = 4*8 + 4*4 + 1, 81 = 8*8 + 4*4 + 1, 113 = 12*8 + 4*4 + 1 (the UI's
+// MaxDisparity 48, 80, 112).  The dispatcher places the waves of a workgroup on the four SIMDs round-robin
+// (tools/ubench/simd_map.hip), so with nwa and nw - nwa multiples of 4 every SIMD gets the same mix and no SIMD paces
+// the row barrier; uniform plans of these ranges either leave a quarter of the chip idle (7 waves of 8) or need 12-wave
+// workgroups of 4 (measured 10 % slower than 7 x 8).  Both groups run on one ring, one pair of row buffers and the same
+// barriers; the groups differ only in their column-sum registers and operand offsets.
+template <int P, int ND, int H, bool PK, int WB, bool W16, bool TR = false, bool MIX = false>
 __global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
 {
-  if constexpr (TR) {
+  if constexpr (MIX) {
+    static_assert(!TR && W16 && !PK && ND == 8, "mixed chunks: unpacked kernels on the u16 ring, chunks of 8 and 4");
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wv < a.nwa) Cw<P, ND, H, PK, W16, false>::run(a);
+    else Cw<P, ND / 2, H, PK, W16, false>::run(a, a.nwa, a.nwa * ND);
+  } else if constexpr (TR) {
     // per workgroup: the tile with the image's last two columns runs the plain form (Cw::TR3), and for h = 6, 7 so does
     // every tile with an output pixel x whose window starts left of a candidate of this pass (x - h < d: the plain form
     // masks those keys; the triple form carries no masks)
@@ -1085,7 +1117,7 @@ __global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
     bool triple = tx + K::TW + 2 <= a.j.w;
     if constexpr (PK && H > 5) {
       const int ox0 = max(tile == 0 ? a.j.x0 : tx + K::OL, a.j.x0);
-      triple = triple && !(max(ox0, 0) - H < min(a.dbase + a.nw * ND, a.j.maxdisp));
+      triple = triple && !(max(ox0, 0) - H < min(a.dbase + a.slots, a.j.maxdisp));
     }
     if (triple) K::run(a); else Cw<P, ND, H, PK, W16, false>::run(a);
   } else {

@@ -8,7 +8,11 @@
 
 namespace sadhip {
 
-struct Plan { int p, nd, nw; bool pk, extra, w16; };
+// nw waves per workgroup; the LAST nwh of them own nd/2 candidates each (mixed-chunk plans, 0 otherwise), the others nd
+struct Plan {
+  int p, nd, nw; bool pk, extra, w16; int nwh = 0;
+  int slots() const { return (nw - nwh) * nd + nwh * (nd / 2); }     // candidates of the pass without the odd one
+};
 
 // LDS bytes of one workgroup of a plan (the layout at the top of Cw::run): 2h+3 ring rows and the
 // row of zeros, two row-best buffers, the output LUT.

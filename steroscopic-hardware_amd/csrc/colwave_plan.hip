@@ -11,7 +11,7 @@ namespace sadhip {
 size_t plan_lds_bytes(const Plan& pl, int h, int maxdisp)
 {
   const bool swz = pl.p == 8 && !pl.w16 && pl.nd == 8;
-  const size_t tw = 64 * (size_t)pl.p, rw = tw + (size_t)pl.nw * pl.nd + ((pl.w16 || swz) ? 7 : 3) + 1, roww = tw + rw;
+  const size_t tw = 64 * (size_t)pl.p, rw = tw + (size_t)pl.slots() + ((pl.w16 || swz) ? 7 : 3) + 1, roww = tw + rw;
   return (size_t)(2 * h + 4) * roww * (pl.w16 ? 2 : 4) + (size_t)2 * 72 * pl.p * 4 + (size_t)((maxdisp + 1 + 15) & ~15);
 }
 
@@ -23,7 +23,8 @@ int env_int(const char* name, int dflt)
     static const char* const names[] = {"SADHIP_TUNE_ND", "SADHIP_TUNE_NW", "SADHIP_TUNE_P", "SADHIP_TUNE_W16", "SADHIP_TUNE_PK",
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
-                                        "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE"};
+                                        "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE",
+                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -72,34 +73,58 @@ static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int
   // measured: the lane-mask variants spill at ND 12 (B15 D48: 47 vs 36 us) and the unpacked ones
   // lose their u16 ring (B16 D48: 41 vs 37 us)
   const int nd_max = p == 4 ? 24 : ((pk && h <= 5) ? 12 : 8);
-  for (int nd = 4; nd <= nd_max; nd += 4) {
-    if (force_nd && force_nd != nd) continue;
-    for (int nw = 4; nw <= 16; ++nw) {                          // (two-wave workgroups for D <= 48 measured 25-35 % slower)
-      if (force_nw && force_nw != nw) continue;
-      if (p == 4 && nw > 8) continue;                           // measured: 11-16 waves (one workgroup per CU) lose ~10 % to passes of 8 waves
-      if (p == 4 && h > 4 && nd > 16) continue;                 // two-lane halo kernels exist for ND 4, 8, 12, 16
-      if (h > 8 && nd == 8 && nw > 8) continue;                 // ... and so does ND 8 with two-lane halos
-      // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated
-      // for packed h = 7 and unpacked h = 8, chunk size 8, <= 8 waves; unpacked pixels << bitlen(D) must fit)
-      const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 && nd == 8 && nw <= 8 &&
-                       ((pk && h == 7) || (!pk && h >= 8 && maxdisp <= 255));
-      // LDS: (2h+4) ring rows of L[TW] + R[TW + nw*nd + 4 (8)] pixels, two row buffers, the output LUT
-      const size_t lds_plan = plan_lds_bytes(Plan{p, nd, nw, pk, false, w16}, h, maxdisp);
-      if (lds_plan > (size_t)160 * 1024) continue;
-      const int slots = nw * nd;
-      if (slots + 1 < count) continue;
+  // nwh: the last nwh waves carry chunks of nd/2 (mixed-chunk plans: unpacked, u16 ring, nd 8, both groups multiples of 4
+  // so that every SIMD gets the same mix -- 49 = 4*8 + 4*4 + 1, 81 = 8*8 + 4*4 + 1, 113 = 12*8 + 4*4 + 1)
+  auto consider = [&](int nd, int nw, int nwh) {
+      if (force_nw && force_nw != nw) return;
+      if (p == 4 && nw > 8) return;                             // measured: 11-16 waves (one workgroup per CU) lose ~10 % to passes of 8 waves
+      if (p == 4 && h > 4 && nd > 16) return;                   // two-lane halo kernels exist for ND 4, 8, 12, 16
+      // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated for packed h = 7,
+      // chunk size 8, and for unpacked h >= 8, chunk sizes 8 and 4 -- the latter with an even wave count: its ring
+      // rows are whole 16-byte blocks only then; unpacked pixels << bitlen(D) must fit 16 bits).
+      // Chunks of 8 on the u16 ring: up to 8 waves for h = 8 (beyond, the u32 ring's 16-wave workgroups measured 1-3 %
+      // faster: B16 D96 54.7 vs 56.6 us), up to 16 for the two-lane halo kernels, h > 8 (one pass of 11-16 waves instead of
+      // two passes of 8: B21 D96 65.5 -> 59.5 us, D128 76.6 -> 72.8)
+      const int w16_nw8 = env_int("SADHIP_TUNE_W16NW", h > 8 ? 16 : 8);
+      const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 &&
+                       ((nd == 8 && (nw <= w16_nw8 || nwh) && ((pk && h == 7 && !nwh) || (!pk && h >= 8 && maxdisp <= 255))) ||
+                        (nd == 4 && nw % 2 == 0 && env_int("SADHIP_TUNE_W16ND4", 1) != 0 && !pk && h >= 8 && maxdisp <= 255));
+      if (nwh && !(w16 && !pk && nd == 8)) return;
+      if (h > 8 && nd == 8 && nw > 8 && !w16) return;           // ... and so does ND 8 with two-lane halos on the u32 ring (256-VGPR builds: <= 8 waves)
+      // LDS: (2h+4) ring rows of L[TW] + R[TW + slots + 4 (8)] pixels, two row buffers, the output LUT
+      Plan cand{p, nd, nw, pk, false, w16};
+      cand.nwh = nwh;
+      const size_t lds_plan = plan_lds_bytes(cand, h, maxdisp);
+      if (lds_plan > (size_t)160 * 1024) return;
+      const int slots = cand.slots();
+      if (slots + 1 < count) return;
       const bool extra = slots + 1 == count;
-      if (exact && !extra && slots != count) continue;
-      if (!extra && slots - nd >= count && nw > 4) continue;    // a whole wave would be idle
-      const long per_wave = (long)(pk ? 22 : 36) * nd * (p / 4) + 75 + (extra ? 40 * (p / 4) : 0);
+      if (exact && !extra && slots != count) return;
+      if (nwh && !extra && slots != count) return;              // mixed chunks only where they fit exactly
+      if (!extra && slots - nd >= count && nw > 4) return;      // a whole wave would be idle
+      auto per_wave = [&](int ndw, bool x) { return (long)(pk ? 22 : 36) * ndw * (p / 4) + 75 + (x ? 40 * (p / 4) : 0); };
+      // the busiest SIMD: waves go to the SIMDs round-robin (wave i -> SIMD i mod 4, tools/ubench/simd_map.hip); the last
+      // wave carries the odd candidate
+      long simd[4] = {0, 0, 0, 0};
+      for (int i = 0; i < nw; ++i) simd[i % 4] += per_wave(i >= nw - nwh ? nd / 2 : nd, extra && i == nw - 1);
+      const long busiest = std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3]));
       // waves a CU can hold of this plan (LDS; 128 VGPRs = 16 waves for the unpacked kernels): with one
       // 4-wave workgroup per CU nothing hides its latencies (measured: BlockSize 16, D 16 as 4 waves x 4
-      // candidates on a u32 ring, one workgroup per CU, 26.7 us; as 4 x 8 on the u16 ring, three per CU, 20.5)
+      // candidates on a u32 ring, one workgroup per CU, 26.7 us; as 4 x 8 on the u16 ring, three per CU, 20.5;
+      // as 4 x 4 on the u16 ring, round 4: 13.8)
       const long resident = std::min<long>((long)((size_t)160 * 1024 / lds_plan) * nw, pk ? 20 : 16);
       const long pct = resident <= 4 ? 200 : resident <= 8 ? 118 : 100;
-      const long cost = (long)((nw + 3) / 4) * per_wave * 64 * pct / 100 + nw;    // ties: fewer waves
-      if (cost < best_cost) { best_cost = cost; best = Plan{p, nd, nw, pk, extra, w16}; }
-    }
+      // workgroups of more than 8 waves wait more at the row barrier (measured, unpacked: 12 x 4 candidates 36.9 us against
+      // 7 x 8 with a quarter of the SIMD slots idle 33.4)
+      const long big = (!pk && nw > 8) ? 112 : 100;
+      const long cost = busiest * 64 * pct / 100 * big / 100 + nw;    // ties: fewer waves
+      if (cost < best_cost) { best_cost = cost; best = cand; best.extra = extra; }
+  };
+  for (int nd = 4; nd <= nd_max; nd += 4) {
+    if (force_nd && force_nd != nd) continue;
+    for (int nw = 4; nw <= 16; ++nw) consider(nd, nw, 0);       // (two-wave workgroups for D <= 48 measured 25-35 % slower)
+    if (nd == 8 && p == 8 && !pk && env_int("SADHIP_TUNE_MIX", 1) != 0)
+      for (int nwa = 4; nwa <= 12; nwa += 4) consider(8, nwa + 4, 4);
   }
   return best;
 }
@@ -136,7 +161,8 @@ static std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
     if (!pk && ((long long)b1 * b1 * 255 << ksh) >= (1LL << 27)) break;
     const bool exact = pk && h > 5;
     // full passes: 8 waves of ND 16 (P 4) / 16 waves of ND 8 (P 8); two-lane halos: 8 waves of ND 8
-    const int chunk = env_int("SADHIP_TUNE_CHUNK", h <= 8 ? 128 : 64);
+    // (round 4: the two-lane halo kernels too -- 16 waves of 8 on the u16 ring where D <= 255, else 8 waves of 8)
+    const int chunk = env_int("SADHIP_TUNE_CHUNK", (h <= 8 || (!pk && maxdisp <= 255)) ? 128 : 64);
     passes.clear();
     int base = 0, rem = maxdisp + 1;
     while (rem > 0) {

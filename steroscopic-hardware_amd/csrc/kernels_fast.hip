@@ -44,18 +44,21 @@ static int wgs_per_cu(Kernel kernel, int threads, size_t lds, bool* asked = null
 // part: 0 = every tile of the job; 1 = only the tiles before the first one that holds the image's last two
 // columns (the triple-column form, TR); 2 = only the tiles from that one on (the plain form next to it).
 // geom (optional): fill in the launch geometry and return without launching.
-template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false, bool TR = false>
+template <int P, int ND, int H, bool PK, int WB = 1024, bool W16 = false, bool TR = false, bool MIX = false>
 hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, int part = 0, PassGeom* geom = nullptr)
 {
   using K = Cw<P, ND, H, PK, W16, TR>;
+  if ((pl.nwh != 0) != MIX || pl.nwh < 0 || pl.nwh >= pl.nw || (MIX && (pl.nwh % 2 != 0 || pl.nd != ND))) return hipErrorInvalidValue;
   CwArgs a{};
   a.j = j;
   a.nw = pl.nw;
+  a.nwa = pl.nw - pl.nwh;
+  a.slots = a.nwa * ND + pl.nwh * (ND / 2);
   a.xw = pl.extra ? pl.nw - 1 : -1;
   a.ksh = PK ? 16 : 32 - __builtin_clz((unsigned)j.maxdisp);  // unpacked: 2^ksh > maxdisp
   a.pixshift = PK ? 0 : a.ksh;
   a.dbase = io.dbase; a.kin = io.kin; a.kout = io.kout; a.kw = io.kw;
-  a.dpad = pl.nw * ND + K::XOFF;                              // keeps every lane's R operands 16-byte aligned
+  a.dpad = a.slots + K::XOFF;                                 // keeps every lane's R operands 16-byte aligned (u16 ring, chunks of 4: 8-byte)
   const int RW = K::TW + a.dpad + 1;
   // Row streaming and output are shared by the waves.  The wave that carries the odd candidate does
   // ~12 % more arithmetic per row than the others (9 candidates against 8) and every wave waits for it at
@@ -88,6 +91,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   Plan plk = pl; plk.p = P; plk.nd = ND; plk.pk = PK; plk.w16 = W16;
   const size_t lds = plan_lds_bytes(plk, H, j.maxdisp) + (size_t)env_int("SADHIP_TUNE_LDSPAD", 0);   // tuning aid: cap workgroups per CU
   if (lds > 160 * 1024 || lds < (size_t)(K::NR + 1) * (K::TW + RW) * sizeof(typename K::Px)) return hipErrorInvalidValue;
+  if (((size_t)(K::TW + RW) * sizeof(typename K::Px)) % 16 != 0) return hipErrorInvalidValue;   // ring rows are whole 16-byte blocks (u16 ring with ND 4: even wave counts)
   if (dry) return hipSuccess;
   // Strips per frame.  Each strip repeats 2h warm-up rows (+ set-up), so strips should be tall; but the
   // chip must be filled, a launch that is a little more than one round of workgroups waits for its tail,
@@ -99,7 +103,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   const int min_rows = env_int("SADHIP_TUNE_MINROWS", 8);
   long nstrips;
   bool asked = false;
-  const int per_cu = wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, TR>, 64 * pl.nw, lds, &asked);
+  const int per_cu = wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, TR, MIX>, 64 * pl.nw, lds, &asked);
   if (env_int("SADHIP_TUNE_LEGACY_STRIPS", 0)) {                // round 2's constants, for comparison
     const long want = env_int("SADHIP_TUNE_WGS", P == 4 ? 512 : 256);
     const long rows_target = env_int("SADHIP_TUNE_ROWS", 48 * H), wg_max = env_int("SADHIP_TUNE_WGMAX", 4096);
@@ -137,7 +141,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
       else (void)hipMemsetAsync(aa.stamps, 0, nwg * 16 * 8 * sizeof(unsigned long long), s);
     }
 #endif
-    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, TR>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
+    hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, TR, MIX>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef SADHIP_STAMPS
@@ -203,8 +207,8 @@ int describe_fast(const Job& j, char* buf, int cap, bool geometry)
     const int next = k + 1 < passes.size() ? passes[k + 1].dbase : j.maxdisp + 1;
     const size_t lds = plan_lds_bytes(pl, h, j.maxdisp);
     if (buf && at < cap)
-      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d lds=%zu",
-                     passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, lds);
+      at += snprintf(buf + at, (size_t)(cap - at), "dbase=%d count=%d p=%d nd=%d nw=%d packed=%d extra=%d w16=%d nwh=%d lds=%zu",
+                     passes[k].dbase, next - passes[k].dbase, pl.p, pl.nd, pl.nw, (int)pl.pk, (int)pl.extra, (int)pl.w16, pl.nwh, lds);
     if (geometry) {
       PassGeom g;
       if (launch_pass(j, pl, PassIo{passes[k].dbase, nullptr, nullptr, j.x1 - j.x0}, nullptr, false, &g) != hipSuccess) return -1;
@@ -219,10 +223,15 @@ int describe_fast(const Job& j, char* buf, int cap, bool geometry)
 static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, PassGeom* geom)
 {
   const int h = j.block / 2;
-  if (pl.w16 && pl.pk && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry, 0, geom);
-  if (pl.w16 && !pl.pk && h == 8) return launch_t<8, 8, 8, false, 1024, true>(j, pl, io, s, dry, 0, geom);   // 128-VGPR build: two workgroups per CU
-#define SADHIP_W16U(HH) if (pl.w16 && !pl.pk && h == HH) return launch_t<8, 8, HH, false, 1024, true>(j, pl, io, s, dry, 0, geom)
-  SADHIP_W16U(9); SADHIP_W16U(10); SADHIP_W16U(11); SADHIP_W16U(12); SADHIP_W16U(13); SADHIP_W16U(14); SADHIP_W16U(15);
+  if ((pl.w16 && pl.p != 8) || (pl.nwh && !pl.w16)) return hipErrorInvalidValue;
+  if (pl.w16 && pl.pk && pl.nd == 8 && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry, 0, geom);
+  // unpacked on the u16 ring, 128-VGPR builds (up to 16 waves per workgroup, two or three workgroups per CU): chunks of 8 and of 4
+#define SADHIP_W16U(HH) \
+  if (pl.w16 && !pl.pk && pl.nd == 8 && pl.nwh && h == HH) return launch_t<8, 8, HH, false, 1024, true, false, true>(j, pl, io, s, dry, 0, geom); \
+  if (pl.w16 && !pl.pk && pl.nd == 8 && h == HH) return launch_t<8, 8, HH, false, 1024, true>(j, pl, io, s, dry, 0, geom); \
+  if (pl.w16 && !pl.pk && pl.nd == 4 && h == HH) return launch_t<8, 4, HH, false, 1024, true>(j, pl, io, s, dry, 0, geom)
+  SADHIP_W16U(8); SADHIP_W16U(9); SADHIP_W16U(10); SADHIP_W16U(11); SADHIP_W16U(12); SADHIP_W16U(13); SADHIP_W16U(14); SADHIP_W16U(15);
+  if (pl.w16) return hipErrorInvalidValue;
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
   if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s, dry, 0, geom)
   // BlockSize 9: triple-column form for the tiles left of the image's last two columns, plain form for the rest

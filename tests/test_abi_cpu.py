@@ -95,11 +95,14 @@ def test_no_column_wave_kernel_spills():
         name = b.split()[0]
         val = lambda k: int(re.search(k + r": (\d+)", b).group(1))
         sc, ss, vs = val(r"ScratchSize \[bytes/lane\]"), val("SGPRs Spill"), val("VGPRs Spill")
-        m = re.search(r"k_colwaveILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi\d+ELb\dELb(\d)E", name)   # <P, ND, H, PK, WB, W16, TR>
-        lane_mask_family = bool(m) and m.group(4) == "1" and m.group(3) in ("6", "7")
+        m = re.search(r"k_colwaveILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi\d+ELb\dELb(\d)ELb(\d)E", name)   # <P, ND, H, PK, WB, W16, TR, MIX>
+        assert m, name
+        lane_mask_family = m.group(4) == "1" and m.group(3) in ("6", "7")
         # the BlockSize-9 kernels hold two forms behind a per-workgroup branch (triple-column / plain, Cw::TR3)
-        two_form_family = bool(m) and m.group(5) == "1"
-        if sc or vs or (ss and not (lane_mask_family or two_form_family)) or ss > (16 if two_form_family else 12):
+        two_form_family = m.group(5) == "1"
+        # round 4: the mixed-chunk kernels hold the chunk-8 and the chunk-4 row loop behind a per-wave branch (1 parked SGPR)
+        mixed_family = m.group(6) == "1"
+        if sc or vs or (ss and not (lane_mask_family or two_form_family or mixed_family)) or ss > (18 if two_form_family else 2 if mixed_family else 12):
             bad.append((name, sc, ss, vs))
     assert not bad, bad
 
@@ -217,10 +220,10 @@ def test_whole_ui_parameter_grid_plans_on_the_fast_kernel():
 def test_planner_invariants_over_the_parameter_space():
     """plan_job (colwave_plan.hip) through sadhip_plan_describe: passes tile [0, D] without gaps, stay
     inside the launch limits the kernel assumes, and keep the properties the kernel relies on."""
-    seen, p4_first = set(), set()
+    seen, p4_first, mixed = set(), set(), set()
     for block in range(2, 32):
         hh = block // 2
-        for maxdisp in list(range(1, 70)) + [95, 96, 100, 127, 128, 129, 160, 192, 193, 200, 255, 256, 257, 300, 511, 512, 1000, 4096]:
+        for maxdisp in list(range(1, 70)) + [80, 95, 96, 100, 112, 127, 128, 129, 144, 160, 176, 192, 193, 200, 208, 240, 255, 256, 257, 300, 511, 512, 1000, 4096]:
             w = max(1920, maxdisp + 2 * hh + 40)
             plan = capi.plan_describe(w, 64, block, maxdisp)
             assert (len(plan) > 0) == (capi.kernel_kind(w, 64, block, maxdisp) == 1)
@@ -228,8 +231,11 @@ def test_planner_invariants_over_the_parameter_space():
             for i, ps in enumerate(plan):
                 assert ps["dbase"] == at and ps["count"] >= 1
                 at += ps["count"]
-                slots = ps["nw"] * ps["nd"]
+                slots = (ps["nw"] - ps["nwh"]) * ps["nd"] + ps["nwh"] * ps["nd"] // 2
                 assert 4 <= ps["nw"] <= 16 and ps["nd"] % 4 == 0 and ps["p"] in (4, 8)
+                if ps["nwh"]:                                               # mixed chunks: u16 ring, 8 + 4, both groups whole SIMD rounds, exact
+                    assert ps["w16"] and not ps["packed"] and ps["nd"] == 8 and ps["nwh"] == 4 and (ps["nw"] - 4) % 4 == 0 and slots + ps["extra"] == ps["count"]
+                    mixed.add((hh, maxdisp))
                 assert ps["lds"] <= 160 * 1024
                 assert ps["extra"] == (1 if slots + 1 == ps["count"] else 0)
                 assert slots + ps["extra"] >= ps["count"]
@@ -246,15 +252,22 @@ def test_planner_invariants_over_the_parameter_space():
                     assert hh >= 3 and ps["p"] == 8
                     assert ((2 * hh + 1) ** 2 * 255 << maxdisp.bit_length()) < (1 << 27)
                 if ps["w16"]:
-                    assert ps["p"] == 8 and ps["nd"] == 8 and ps["nw"] <= 8 and (ps["packed"] or maxdisp <= 255)
+                    assert ps["p"] == 8 and ps["nd"] in (4, 8) and (ps["packed"] or maxdisp <= 255)
+                    if ps["nd"] == 4:
+                        assert not ps["packed"] and ps["nw"] % 2 == 0      # ring rows stay whole 16-byte blocks
+                    elif hh <= 8 and not ps["nwh"]:
+                        assert ps["nw"] <= 8                                # beyond, the u32 ring (h = 8) measured faster
                 seen.add((ps["p"], ps["nd"], ps["packed"], ps["w16"]))
             assert at in (0, maxdisp + 1)
-    assert {(4, 16, 1, 0), (8, 8, 0, 1), (8, 4, 0, 0)} <= seen
+    assert {(4, 16, 1, 0), (8, 8, 0, 1), (8, 4, 0, 0), (8, 4, 0, 1)} <= seen
+    assert {(hh, d) for hh in range(8, 16) for d in (48, 80, 112, 176, 208, 240)} <= mixed     # the UI's D = 16 (mod 32) for BlockSize >= 16
     assert {(5, 4), (6, 4), (7, 4)} <= p4_first                 # h = 5..7 run the P = 4 kernels ...
     for block, maxdisp in ((15, 128), (15, 64), (13, 96), (11, 128), (11, 16)):
         assert [ps["p"] for ps in capi.plan_describe(1920, 1080, block, maxdisp)] == [4]
     assert (7, 8) in p4_first or (6, 8) in p4_first             # ... and fall back to P = 8 for a D without an exact P = 4 plan
-    assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0,
+    assert capi.plan_describe(1920, 1080, 16, 16) == [dict(dbase=0, count=17, p=8, nd=4, nw=4, packed=0, extra=1, w16=1, nwh=0,
+                                                          lds=capi.plan_describe(1920, 1080, 16, 16)[0]["lds"])]
+    assert capi.plan_describe(1920, 1080, 9, 64) == [dict(dbase=0, count=65, p=4, nd=16, nw=4, packed=1, extra=1, w16=0, nwh=0,
                                                          lds=capi.plan_describe(1920, 1080, 9, 64)[0]["lds"])]
 
 

@@ -405,6 +405,41 @@ def test_every_plan_shape(ctx):
                 assert np.array_equal(got, exp), (name, block, D)
 
 
+def test_u16_ring_chunks_of_four_and_mixed_chunk_plans(ctx):
+    """Round 4: the unpacked kernels (BlockSize >= 16) for 16k+1 candidates with k odd.  MaxDisparity 16 plans as 4 waves x 4
+    candidates + 1 on the u16 ring (8-byte operand reads); 48 / 80 / 112 as MIXED workgroups -- 4 / 8 / 12 waves of 8
+    candidates followed by 4 waves of 4, + 1 -- and 176 / 208 / 240 with such a pass after a full pass of 128.  Random,
+    shifted, extreme (largest SADs) and flat frames, widths of one to three tiles and every w mod 8, against the oracle."""
+    rng = np.random.default_rng(44)
+    for block, w in ((16, 437), (17, 700), (19, 1030), (23, 517), (27, 941), (31, 1203)):
+        hh = block // 2
+        hgt = 2 * hh + 9
+        for D in (16, 48, 80, 112, 176, 208, 240):
+            pl = capi.plan_describe(w, hgt, block, D)
+            assert pl and pl[-1]["w16"] == 1 and pl[-1]["extra"] == 1, (block, D, pl)
+            assert pl[-1]["nwh"] == (0 if D == 16 else 4) and (pl[-1]["nd"], pl[-1]["nw"]) == ((4, 4) if D == 16 else (8, {48: 8, 80: 12, 112: 16}[D % 128])), (block, D, pl)
+            L = rng.integers(0, 256, size=(4, hgt, w), dtype=np.uint8)
+            R = rng.integers(0, 256, size=(4, hgt, w), dtype=np.uint8)
+            R[1] = np.roll(L[1], -min(D, 29), axis=1)
+            L[2] = 255; R[2] = 0; R[2][:, w // 3:] = 255; R[2][:, 2 * w // 3:] = 0
+            L[3] = 91; R[3] = 91
+            for i in range(4):
+                got = ctx.disparity(L[i], R[i], block, D, capi.FLAG_RAW)
+                assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+                assert np.array_equal(got, _expect(L[i], R[i], block, D, raw=True)), (block, w, D, i)
+    # and as a device-resident batch at 1080p width (several tiles, the batched strip geometry), against the generic kernel
+    import torch
+    for block, D in ((16, 48), (21, 80), (31, 112), (16, 16)):
+        g = torch.Generator(device="cuda").manual_seed(block * 1000 + D)
+        Ls = torch.randint(0, 256, (6, 70, 1920), dtype=torch.uint8, device="cuda", generator=g)
+        Rs = torch.roll(Ls, -17, dims=2) ^ (torch.randint(0, 16, Ls.shape, device="cuda", generator=g) == 0).to(torch.uint8)
+        a, b = torch.empty_like(Ls), torch.empty_like(Ls)
+        ctx.disparity_dev(Ls, Rs, a, block, D)
+        ctx.disparity_dev(Ls, Rs, b, block, D, capi.FLAG_FORCE_GENERIC)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (block, D)
+
+
 def test_multi_pass_disparity_ranges(ctx):
     """D+1 candidates beyond the 16 waves of a workgroup run as several launches that hand a u32 key
     per pixel from pass to pass (colwave_plan.hip, plan_job): every UI value of MaxDisparity
