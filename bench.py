@@ -15,7 +15,8 @@ collective; the two parameters are broadcast from rank 0 over RCCL.
 
 Outside the timed headline, at N = 1: "host_fed" (sadhip_disparity_batch_u8 on frames in host memory,
 page-locked and pageable -- what a Go / C++ host calls; PCIe-inclusive, never `value`) and "pool"
-(sadhip_pool_batch_u8 over every visible device).
+(sadhip_pool_batch_u8 over G = 1, 2, 4, 8 of the visible devices), and the roofline's HBM traffic / VALU instruction count measured in
+the run itself by three child passes under rocprofv3 --pmc (--no-live-counters: the committed profile instead).
 
 Prints ONE JSON line on rank 0: metric = stereo pairs/s (whole job), plus ms/frame, the HBM
 roofline object for the disparity kernel, candidate evaluations/s, and the CPU baseline
@@ -80,6 +81,66 @@ def _usable_cpus():
         except (OSError, ValueError, IndexError):
             continue
     return n
+
+
+def _go_toolchain():
+    """BASELINE.md 3.1 / SURVEY 8(d)(1): with a Go toolchain on the box the CPU baseline would be the reference itself
+    (a loop like examples/run.stream.go:46-62 over pkg/despair).  Probed, never assumed: the version string, or None."""
+    import shutil
+    import subprocess
+    go = shutil.which("go")
+    if not go:
+        return None
+    try:
+        return subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        return None
+
+
+def _live_counters(frames, timeout_s=240):
+    """HBM traffic and VALU instruction count of the headline launch, measured IN THIS RUN: three child processes
+    `rocprofv3 --pmc <one counter set> -- python3 bench.py --headline-only` (separate passes, counters sampled on the
+    disparity kernel only, the program directly after `--`), each launching the same `frames`-pair batch.  Returns
+    {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "SQ_INSTS_VALU": n, ...} per launch (mean over the child's launches), or
+    {"error": ...}.  MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE in KB, gfx950 FETCH_SIZE x2."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    got, t_all = {}, time.perf_counter()
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU"]):
+        td = tempfile.mkdtemp(prefix="sadhip_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--kernel-trace", "--kernel-include-regex", "k_colwave|k_disparity", "--pmc", "GRBM_GUI_ACTIVE", *counters,
+                   "--output-format", "csv", "-d", td, "-o", "pmc", "--",
+                   sys.executable, os.path.join(REPO, "bench.py"), "--headline-only", "--steps", "2", "--warmup", "1",
+                   "--frames-per-gpu", str(frames)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {' '.join(counters)}: exit {r.returncode}, {len(files)} csv; " + (r.stderr or r.stdout)[-300:]}
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if "k_colwave" in row["Kernel_Name"] or "k_disparity" in row["Kernel_Name"]:
+                    d = per.setdefault(row["Dispatch_Id"], {})
+                    d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return {"error": "no disparity kernel dispatch in the counter csv"}
+            for c in counters + ["GRBM_GUI_ACTIVE"]:
+                vals = [d[c] for d in per.values() if c in d]
+                if vals:
+                    got[c] = sum(vals) / len(vals)
+            got["launches_sampled"] = len(per)
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+            return {"error": repr(e)[:300]}
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    got["seconds"] = time.perf_counter() - t_all
+    return got
 
 
 def _time_reference_c(ctx, sha):
@@ -172,16 +233,23 @@ def _host_legs(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf):
                                         "matches_device_resident": okp,
                                         "note": "2-D copies through the HIP runtime's own staging (the cgo shim's case)"}
         legs["host_fed"]["single_call_ms"]["pageable"] = onep * 1e3
-        # the native pool over every visible device (frame i -> device i mod G), same page-locked frames
+        # the native pool (frame i -> device i mod G), same page-locked frames, for G = 1, 2, 4, 8 of the visible devices:
+        # SURVEY 8(e) "(ii) host-fed" -- the curve that is expected to flatten at the host's PCIe / memory limit
         ndev = capi.device_count()
-        devices = [local] if ndev <= 1 else list(range(ndev))
-        with capi.Pool(devices, W, H) as pool:
-            dt, ok = timed(lambda: pool.batch(lefts, rights, block, maxdisp, flags, outs=outs))
-            k_sum, wall = pool.last_timing()
-        legs["pool"] = {"value": nf / dt, "unit": "pairs/s", "frames": nf, "devices": devices, "pcie_gb_per_s": 3 * frame * nf / dt / 1e9,
-                        "entry": "sadhip_pool_batch_u8", "memory": "page-locked (sadhip_host_alloc)", "kernel_ms_sum": k_sum,
-                        "matches_device_resident": ok,
-                        "note": "one context + host thread per device, frame i -> device i mod G; on a one-GPU box this is one context"}
+        legs["pool"] = []
+        for g in [g for g in (1, 2, 4, 8) if g <= max(ndev, 1)]:
+            devices = [local] if g == 1 else list(range(g))
+            with capi.Pool(devices, W, H) as pool:
+                dt, ok = timed(lambda: pool.batch(lefts, rights, block, maxdisp, flags, outs=outs))
+                k_sum, wall = pool.last_timing()
+                placement = pool.describe()
+            legs["pool"].append({"value": nf / dt, "unit": "pairs/s", "frames": nf, "devices": devices, "pcie_gb_per_s": 3 * frame * nf / dt / 1e9,
+                                 "entry": "sadhip_pool_batch_u8", "memory": "page-locked (sadhip_host_alloc)", "kernel_ms_sum": k_sum,
+                                 "matches_device_resident": ok, "workers": placement})
+        legs["pool_note"] = ("one context + host thread per device, frame i -> device i mod G, each worker thread pinned to the CPUs of its "
+                             "device's NUMA node (workers[].cpus; best effort); the frames here are ONE page-locked block allocated by the "
+                             "calling thread, so on a two-socket host half the devices read across the socket link -- a deployment allocates "
+                             "each device's frames from its worker's node")
     return legs
 
 
@@ -194,6 +262,9 @@ def main():
     ap.add_argument("--weak", action="store_true", help="weak scaling: 1024 pairs per GPU whatever N is")
     ap.add_argument("--host-frames", type=int, default=256, help="frames of the host-fed / pool legs (N = 1 only; 0 = skip them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not run the three rocprofv3 --pmc child passes (N = 1): roofline.traffic then comes from the committed "
+                         "profiles/traffic.json, labelled as such")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the warm-up and timed launches of the headline workload (no latency / 128-pair / host-fed / CPU legs): "
                          "under rocprofv3 --kernel-trace --stats the kernel's average duration is then the headline launch's")
@@ -261,7 +332,7 @@ def main():
     avg_launch_ms = sum(launch_ms) / len(launch_ms)
 
     if args.headline_only:
-        args.no_cpu_baseline, args.host_frames = True, 0
+        args.no_cpu_baseline, args.host_frames, args.no_live_counters = True, 0, True
     # single-pair latency (ms/frame of one 1080p pair on an otherwise idle GPU)
     one_ms = []
     for _ in range(0 if args.headline_only else 20):
@@ -298,6 +369,8 @@ def main():
         "value": total_frames / elapsed,
         "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "distributed": {"backend": (dist.get_backend() if dist is not None else None), "world_size": (dist.get_world_size() if dist is not None else 1),
+                        "collectives": "2 x int32 parameter broadcast, one barrier either side of the timed region, max-over-ranks of the time; none on the data path"},
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
@@ -371,6 +444,30 @@ def main():
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
+    # ... and the same counters measured IN THIS RUN (child processes under rocprofv3 --pmc, N = 1): when they succeed they
+    # replace the committed figures above, which stay in the line as "committed_profile" for comparison
+    if world == 1 and not args.no_live_counters and res["config"]["kernel_kind"] == 1:
+        lc = _live_counters(F)
+        if "error" in lc or not {"FETCH_SIZE", "WRITE_SIZE"} <= set(lc):
+            res["roofline"]["live_counters"] = lc
+        else:
+            committed = {"traffic": res["roofline"].get("traffic"), "traffic_source": res["roofline"].get("traffic_source")}
+            live_bytes = int(lc["FETCH_SIZE"] * 1024 * 2 + lc["WRITE_SIZE"] * 1024)
+            res["roofline"]["traffic"] = live_bytes
+            res["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate child passes over "
+                                                 "bench.py --headline-only, %d pairs per launch, mean of %d launches), FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KB"
+                                                 % (F, lc.get("launches_sampled", 0)))
+            res["roofline"]["traffic_over_algorithmic"] = live_bytes / alg_bytes_per_launch
+            res["roofline"]["committed_profile"] = committed
+            res["roofline"]["live_counters"] = lc
+            if "SQ_INSTS_VALU" in lc and "valu" in res["roofline"]:
+                v = res["roofline"]["valu"]
+                ginst = lc["SQ_INSTS_VALU"] / (avg_launch_ms * 1e-3) / 1e9
+                v.update({"achieved": ginst, "insts_per_launch": int(lc["SQ_INSTS_VALU"]), "frac_of_vector_peak": ginst / VECTOR_PEAK_GWINST,
+                          "frac_of_mix_ceiling": ginst / v["mix_ceiling"], "insts_source": "SQ_INSTS_VALU measured in this run (child pass under rocprofv3 --pmc)",
+                          "valu_per_64_candidates": lc["SQ_INSTS_VALU"] / (cands * F / 64.0),
+                          "simd_cycles_per_valu_inst": SIMDS * CLOCK_GHZ * 1e9 * (avg_launch_ms * 1e-3) / lc["SQ_INSTS_VALU"]})
+
     if world == 1 and args.host_frames > 0:
         try:
             res.update(_host_legs(sha, ctx, local, Ls, Rs, out, block, maxdisp, args.flags, min(args.host_frames, F)))
@@ -412,6 +509,8 @@ def main():
         ok = ok1 and okn
         res["cpu_baseline"] = {
             "value": nn / wn, "unit": "pairs/s", "cores": ncpu, "kind": "port", "cpu_model": model, "host_logical_cpus": host_cpus,
+            # "port" because the reference itself (Go) cannot run here: probed in this run, not assumed
+            "go_toolchain": _go_toolchain(),
             "sample": f"{nn} full {W}x{H} pairs (frame seeds 1000..{1000 + nn - 1} of this rank), literal restatement of "
                       f"pkg/despair sad.go:55-94 in C, {ncpu} threads over output.go row bands, {wn:.2f} s wall = {wn * ncpu:.0f} CPU-seconds"
                       + ("" if args.cpu_threads else f"; {ncpu} = this tenant's share of the {host_cpus}-thread host -- the all-thread run was measured in round 2 "

@@ -42,9 +42,12 @@
 extern "C" {
 #endif
 
-#define SADHIP_ABI_VERSION 3   /* 2: flag validation, MIRROR_VERILOG, sadhip_last_kernel_kind, sadhip_pool_*;
+#define SADHIP_ABI_VERSION 4   /* 2: flag validation, MIRROR_VERILOG, sadhip_last_kernel_kind, sadhip_pool_*;
                                 * 3: sadhip_disparity_lr_u8 (left / right images of different sizes), sadhip_host_* (page-locked
-                                *    host memory), sadhip_plan_describe_batch */
+                                *    host memory), sadhip_plan_describe_batch;
+                                * 4: sadhip_pool_describe (NUMA placement of the pool's worker threads), sadhip_host_register
+                                *    refuses overlapping ranges, the generic kernel's work bound (SADHIP_GENERIC_MAX_WORK),
+                                *    "nwh" in the plan lines */
 
 #if defined(__GNUC__)
 #define SADHIP_API __attribute__((visibility("default")))
@@ -68,6 +71,14 @@ extern "C" {
 
 #define SADHIP_MAX_BLOCK     255
 #define SADHIP_MAX_MAXDISP  4096
+/* Work bound of the generic path (ABI 4).  Parameter sets the column-wave kernel does not cover (BlockSize > 31, a right image
+ * smaller than the left one, ...) and SADHIP_FLAG_FORCE_GENERIC run a one-thread-per-pixel kernel whose cost per pixel is the
+ * reference's own: (2*(block/2)+1)^2 * (maxdisp+1) byte differences.  Above this many per pixel the library runs the same
+ * function with running sums instead (vertical column sums per thread, prefix sums across the workgroup): O(maxdisp) per
+ * pixel whatever the block size -- 1920x1080, block 63, maxdisp 64 in milliseconds where the naive kernel needs 0.2 s, and no
+ * legal call (block <= 255, maxdisp <= 4096) costs more than about 1e-4 ms per pixel-candidate.  sadhip_kernel_kind() /
+ * sadhip_last_kernel_kind() report 5 for that form, 0 for the naive one. */
+#define SADHIP_GENERIC_MAX_WORK 65536
 
 /* sadhip_disparity_* "flags" argument.  Bits not defined here, or more than one MIRROR_* bit,
  * are rejected with SADHIP_ERR_ARG. */
@@ -216,7 +227,7 @@ SADHIP_API int sadhip_last_timing(sadhip_ctx* ctx, float* kernel_ms, float* tota
 
 /* Which kernel a given parameter set dispatches to (diagnostics / tests; needs no GPU):
  * 0 = generic, 1 = column-wave fast kernel, 2 / 3 / 4 = the sad.c / test.py / compute_SAD.v mirror
- * kernels; -1 on invalid parameters or flags.  The answer is binding: a job planned for the
+ * kernels, 5 = generic in its running-sum form (per-pixel work above SADHIP_GENERIC_MAX_WORK); -1 on invalid parameters or flags.  The answer is binding: a job planned for the
  * column-wave kernel either runs on it or fails with SADHIP_ERR_HIP -- there is no silent fallback. */
 SADHIP_API int sadhip_kernel_kind(int w, int h, int block, int maxdisp, unsigned flags);
 
@@ -250,7 +261,9 @@ SADHIP_API int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, 
  * ranges and then uses asynchronous linear copies; results are identical either way.  Free / unregister a
  * range only when no call that was given pointers into it is still running (every entry point has finished
  * with the caller's memory when it returns); a range that disappears under a running call is not an error --
- * the copies fall back to the pageable path -- but its memory must of course stay valid. */
+ * the copies fall back to the pageable path -- but its memory must of course stay valid.
+ * The known ranges are DISJOINT: sadhip_host_register of memory that overlaps a sadhip_host_alloc block or an earlier
+ * registration (a sub-range, a super-range, a partial overlap) returns SADHIP_ERR_ARG and registers nothing. */
 SADHIP_API int sadhip_host_alloc(size_t bytes, void** out);
 SADHIP_API int sadhip_host_free(void* p);
 SADHIP_API int sadhip_host_register(void* p, size_t bytes);
@@ -274,6 +287,15 @@ SADHIP_API int sadhip_pool_batch_u8(sadhip_pool* pool, int n,
                          uint8_t* const* outs, int ostride);
 /* kernel_ms_sum: device time of the kernels summed over the pool's devices; wall_ms: of the call */
 SADHIP_API int sadhip_pool_last_timing(sadhip_pool* pool, float* kernel_ms_sum, float* wall_ms);
+/* Host placement of the pool (ABI 4).  Each worker thread -- the thread that issues its device's copies and launches -- is
+ * pinned at creation to the CPUs of the device's NUMA node: PCI bus id (hipDeviceGetPCIBusId) ->
+ * /sys/bus/pci/devices/<id>/local_cpulist, cut down to the CPUs the process itself may use; best effort (a host without
+ * that sysfs file, or an empty intersection, leaves the thread where the scheduler puts it).  Writes one line per entry,
+ * "entry=<i> device=<ordinal> pci=<bus id> numa_node=<n or -1> pinned=<0|1> cpus=<list or ->", into buf (NUL-terminated,
+ * truncated to cap).  The frames of a batch should come from memory of the same node: allocate (sadhip_host_alloc) and
+ * first-touch device i's frames -- i, i + G, ... -- from a thread running on entry i's cpus; frames in one block
+ * allocated by one thread cross the socket link for half the devices of a two-socket host. */
+SADHIP_API int sadhip_pool_describe(const sadhip_pool* pool, char* buf, int cap);
 
 #ifdef __cplusplus
 }

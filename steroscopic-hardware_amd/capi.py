@@ -24,8 +24,9 @@ FLAG_FORCE_GENERIC = 2
 FLAG_MIRROR_SADC = 4
 FLAG_MIRROR_TESTPY = 8
 FLAG_MIRROR_VERILOG = 16
-KIND_GENERIC, KIND_COLWAVE, KIND_MIRROR_SADC, KIND_MIRROR_TESTPY, KIND_MIRROR_VERILOG = range(5)
-ABI_VERSION = 3
+KIND_GENERIC, KIND_COLWAVE, KIND_MIRROR_SADC, KIND_MIRROR_TESTPY, KIND_MIRROR_VERILOG, KIND_GENERIC_SLIDING = range(6)
+GENERIC_MAX_WORK = 65536
+ABI_VERSION = 4
 MAX_BLOCK = 255
 MAX_MAXDISP = 4096
 
@@ -74,6 +75,7 @@ SYMBOLS = {
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
                                        C.POINTER(C.c_void_p), C.c_int]),
     "sadhip_pool_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sadhip_pool_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
 }
 
 _LIB = None
@@ -429,6 +431,17 @@ class Pool:
         n, w, h, ls, rs, outs, pa, pb, po = _frames(lefts, rights, outs)
         _check(lib().sadhip_pool_batch_u8(self._h, n, pa, pb, w, h, ls, rs, block, maxdisp, flags, po, w))
         return outs
+
+    def describe(self):
+        """Host placement of the pool's workers (sadhip_pool_describe): list of dicts entry, device, pci, numa_node,
+        pinned (worker thread pinned to the CPUs of its device's NUMA node), cpus."""
+        buf = C.create_string_buffer(8192)
+        _check(lib().sadhip_pool_describe(self._h, buf, len(buf)))
+        out = []
+        for line in buf.value.decode().splitlines():
+            d = dict(f.split("=", 1) for f in line.split())
+            out.append({k: (int(v) if k in ("entry", "device", "numa_node", "pinned") else v) for k, v in d.items()})
+        return out
 
     def last_timing(self):
         k, t = C.c_float(0), C.c_float(0)

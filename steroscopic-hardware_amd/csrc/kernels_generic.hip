@@ -145,10 +145,20 @@ hipError_t launch_mirror(const Job& j, int mode, hipStream_t s)
   return hipSuccess;
 }
 
+// The naive kernel above costs (2h+1)^2 * (D+1) byte differences per pixel.  Beyond SADHIP_GENERIC_MAX_WORK the
+// running-sum kernel (kernels_sliding.hip) computes the same function in O(D) per pixel: a legal call (BlockSize up to
+// 255, MaxDisparity up to 4096, any frame size) can no longer hold the GPU for minutes.
+bool generic_uses_sliding(int block, int maxdisp)
+{
+  const long long b1 = 2 * (block / 2) + 1;
+  return b1 * b1 * ((long long)maxdisp + 1) > (long long)SADHIP_GENERIC_MAX_WORK;
+}
+
 hipError_t launch_generic(const Job& j, hipStream_t s)
 {
   const int rw = j.x1 - j.x0, rh = j.y1 - j.y0;
   if (rw <= 0 || rh <= 0 || j.n <= 0) return hipSuccess;
+  if (generic_uses_sliding(j.block, j.maxdisp)) return launch_sliding(j, s);
   // grid.z is limited to 65535: split very large batches
   for (int f0 = 0; f0 < j.n; f0 += 32768) {
     Job jj = j;

@@ -5,6 +5,8 @@
 #include "sadhip_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -94,11 +96,26 @@ bool is_pinned(const void* p, size_t bytes)
   return a >= it->lo && a + bytes <= it->hi;
 }
 
-void pin_insert(void* p, size_t bytes, bool owned)
+// false: [p, p + bytes) overlaps a range already known (the registry stays sorted by lo and DISJOINT: is_pinned looks at
+// one predecessor only, pin_remove identifies a range by its start)
+bool pin_insert(void* p, size_t bytes, bool owned)
 {
   const PinnedRange r{(uintptr_t)p, (uintptr_t)p + bytes, owned};
   std::unique_lock<std::shared_mutex> lk(g_pin_mu);
-  g_pins.insert(std::upper_bound(g_pins.begin(), g_pins.end(), r.lo, [](uintptr_t v, const PinnedRange& q) { return v < q.lo; }), r);
+  auto it = std::upper_bound(g_pins.begin(), g_pins.end(), r.lo, [](uintptr_t v, const PinnedRange& q) { return v < q.lo; });
+  if (it != g_pins.end() && it->lo < r.hi) return false;                    // the next range starts inside the new one
+  if (it != g_pins.begin() && std::prev(it)->hi > r.lo) return false;       // the previous range reaches into it
+  g_pins.insert(it, r);
+  return true;
+}
+
+// [p, p + bytes) meets a known range
+bool pin_overlaps(const void* p, size_t bytes)
+{
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  std::shared_lock<std::shared_mutex> lk(g_pin_mu);
+  auto it = std::upper_bound(g_pins.begin(), g_pins.end(), lo, [](uintptr_t v, const PinnedRange& q) { return v < q.lo; });
+  return (it != g_pins.end() && it->lo < hi) || (it != g_pins.begin() && std::prev(it)->hi > lo);
 }
 
 // removes the range that STARTS at p; false when there is none of that kind
@@ -123,8 +140,13 @@ extern "C" int sadhip_host_alloc(size_t bytes, void** out)
     return fail(e == hipErrorOutOfMemory ? SADHIP_ERR_NOMEM : (e == hipErrorNoDevice ? SADHIP_ERR_NO_DEVICE : SADHIP_ERR_HIP),
                 "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
   }
-  try { pin_insert(p, bytes, true); }
+  bool fresh = false;
+  try { fresh = pin_insert(p, bytes, true); }
   catch (const std::bad_alloc&) { (void)hipHostFree(p); return fail(SADHIP_ERR_NOMEM, "registry allocation failed"); }
+  if (!fresh) {                                              // a stale sadhip_host_register entry covers memory the allocator reused
+    (void)hipHostFree(p);
+    return fail(SADHIP_ERR_ARG, "hipHostMalloc returned %p (+%zu), which overlaps a range still registered with sadhip_host_register", p, bytes);
+  }
   *out = p;
   return SADHIP_OK;
 }
@@ -141,13 +163,20 @@ extern "C" int sadhip_host_register(void* p, size_t bytes)
 {
   if (!p) return fail(SADHIP_ERR_NULL, "p is NULL");
   if (bytes == 0) return fail(SADHIP_ERR_ARG, "bytes=0");
+  // ranges are disjoint: a sub-range of a sadhip_host_alloc block (already page-locked) or of an earlier registration is refused
+  if (pin_overlaps(p, bytes)) return fail(SADHIP_ERR_ARG, "[%p, +%zu) overlaps page-locked memory this library already knows", p, bytes);
   const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return fail(e == hipErrorNoDevice ? SADHIP_ERR_NO_DEVICE : SADHIP_ERR_HIP, "hipHostRegister(%p, %zu): %s", p, bytes, hipGetErrorString(e));
   }
-  try { pin_insert(p, bytes, false); }
+  bool fresh = false;
+  try { fresh = pin_insert(p, bytes, false); }
   catch (const std::bad_alloc&) { (void)hipHostUnregister(p); return fail(SADHIP_ERR_NOMEM, "registry allocation failed"); }
+  if (!fresh) {                                              // lost a race with another registration of overlapping memory
+    (void)hipHostUnregister(p);
+    return fail(SADHIP_ERR_ARG, "[%p, +%zu) overlaps page-locked memory this library already knows", p, bytes);
+  }
   return SADHIP_OK;
 }
 
@@ -271,9 +300,14 @@ static int ensure_groups(sadhip_ctx* c)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g.down, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&g.k0);
     if (e == hipSuccess) e = hipEventCreate(&g.k1);
-    if (e == hipSuccess) e = hipMalloc((void**)&g.dL, c->plane * sadhip_ctx::kGroup);
-    if (e == hipSuccess) e = hipMalloc((void**)&g.dR, c->plane * sadhip_ctx::kGroup);
-    if (e == hipSuccess) e = hipMalloc((void**)&g.dO, c->plane * sadhip_ctx::kGroup);
+    // + one row: the frames of a group keep the CALLER's strides, i.e. the last frame may end exactly at plane * kGroup.
+    // No kernel reads a frame past byte (h-1)*stride + w (the column-wave kernels fetch rows with hardware range-checked
+    // buffer loads whose record count is the row width, or with byte loads guarded by col < w; the generic kernels index
+    // x < w only) -- the slack is insurance for that statement, not something a kernel relies on.
+    const size_t gbytes = c->plane * sadhip_ctx::kGroup + c->pitch;
+    if (e == hipSuccess) e = hipMalloc((void**)&g.dL, gbytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&g.dR, gbytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&g.dO, gbytes);
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -404,8 +438,9 @@ extern "C" int sadhip_kernel_kind(int w, int h, int block, int maxdisp, unsigned
   if (flags & SADHIP_FLAG_MIRROR_VERILOG) return KIND_MIRROR_VERILOG;
   Job j{}; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp; j.n = 1;
   j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.lstride = j.rstride = j.ostride = w;
-  if (flags & SADHIP_FLAG_FORCE_GENERIC) return 0;
-  return fast_supported(j) ? 1 : 0;
+  const int generic = generic_uses_sliding(block, maxdisp) ? KIND_GENERIC_SLIDING : KIND_GENERIC;
+  if (flags & SADHIP_FLAG_FORCE_GENERIC) return generic;
+  return fast_supported(j) ? KIND_COLWAVE : generic;
 }
 
 // copy rows [r0,r1) of a host image (stride) into compact staging rows (pitch), staging row 0 = r0
@@ -647,6 +682,12 @@ static int batch_pinned(sadhip_ctx* c, int n, const uint8_t* const* lefts, const
       HIPTRY(hipEventRecord(s.k0, c->s_kern));
       HIPTRY(dispatch(j, flags, c->s_kern));
       HIPTRY(hipEventRecord(s.k1, c->s_kern));
+#ifdef SADHIP_TUNING
+      // diagnostics build only (tests/test_parity_gpu.py): fail after the kernel of group SADHIP_TUNE_FAIL_GROUP has been
+      // queued, with uploads, kernels and downloads of earlier groups still in flight -- the exit below must drain them
+      if (const char* fg = getenv("SADHIP_TUNE_FAIL_GROUP"))
+        if (atoi(fg) == g) return fail(SADHIP_ERR_HIP, "injected failure after the kernel of group %d (diagnostics build)", g);
+#endif
       HIPTRY(hipStreamWaitEvent(c->s_down, s.k1, 0));
       if (int st = download(c->s_down, s.dO, i0, cnt)) return st;
       HIPTRY(hipEventRecord(s.down, c->s_down));
@@ -940,14 +981,87 @@ struct PoolTask {
   unsigned flags = 0;
 };
 
+// Where a device hangs on the host: PCI bus id -> /sys/bus/pci/devices/<id>/{numa_node, local_cpulist}.  Best effort,
+// no dependency beyond sysfs: anything that cannot be read leaves the worker unpinned.
+struct Placement {
+  int device = -1, numa_node = -1;
+  bool pinned = false;
+  char pci[32] = "";
+  char cpus[256] = "";                 // the CPUs the worker thread was pinned to (local_cpulist cut down to the process's affinity mask)
+  cpu_set_t set;
+  bool have_set = false;
+};
+
+static bool parse_cpulist(const char* txt, cpu_set_t* out)
+{
+  CPU_ZERO(out);
+  bool any = false;
+  const char* p = txt;
+  while (*p) {
+    while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+    if (!*p) break;
+    char* end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p || a < 0) return false;
+    long b = a;
+    p = end;
+    if (*p == '-') { b = strtol(p + 1, &end, 10); if (end == p + 1 || b < a) return false; p = end; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, out); any = true; }
+  }
+  return any;
+}
+
+static void format_cpulist(const cpu_set_t* set, char* buf, size_t cap)
+{
+  size_t at = 0;
+  buf[0] = 0;
+  for (int c = 0; c < CPU_SETSIZE; ++c) {
+    if (!CPU_ISSET(c, set)) continue;
+    int e = c;
+    while (e + 1 < CPU_SETSIZE && CPU_ISSET(e + 1, set)) ++e;
+    const int n = e > c ? snprintf(buf + at, cap - at, "%s%d-%d", at ? "," : "", c, e) : snprintf(buf + at, cap - at, "%s%d", at ? "," : "", c);
+    if (n < 0 || (size_t)n >= cap - at) { buf[at] = 0; return; }
+    at += (size_t)n;
+    c = e;
+  }
+}
+
+static Placement find_placement(int device)
+{
+  Placement pl;
+  pl.device = device;
+  char id[32] = "";
+  if (hipDeviceGetPCIBusId(id, (int)sizeof(id), device) != hipSuccess) { (void)hipGetLastError(); return pl; }
+  for (char* c = id; *c; ++c) *c = (char)tolower((unsigned char)*c);      // sysfs names are lower case
+  snprintf(pl.pci, sizeof(pl.pci), "%s", id);
+  char path[128], txt[512];
+  auto slurp = [&](const char* leaf) -> bool {
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/%s", id, leaf);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    const size_t n = fread(txt, 1, sizeof(txt) - 1, f);
+    fclose(f);
+    txt[n] = 0;
+    return n > 0;
+  };
+  if (slurp("numa_node")) pl.numa_node = atoi(txt);
+  cpu_set_t local, mine;
+  if (slurp("local_cpulist") && parse_cpulist(txt, &local) && sched_getaffinity(0, sizeof(mine), &mine) == 0) {
+    CPU_AND(&pl.set, &local, &mine);                             // never leave the CPUs this process was given (cpuset / cgroup)
+    pl.have_set = CPU_COUNT(&pl.set) > 0;
+  }
+  return pl;
+}
+
 struct PoolWorker {
   sadhip_ctx* ctx = nullptr;
+  Placement place;
   int index = 0, stride = 1;           // this worker's frames: index, index + stride, ...
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
   const PoolTask* task = nullptr;      // posted by the caller, cleared by the worker
-  bool quit = false, done = false;
+  bool quit = false, done = false, started = false;
   int status = SADHIP_OK;
   int frames = 0;
   float kernel_ms = 0.f;
@@ -958,6 +1072,15 @@ void pool_worker_main(PoolWorker* me)
 {
   std::vector<const uint8_t*> L, R;
   std::vector<uint8_t*> O;
+  // the thread that issues this device's copies and launches runs on the CPUs next to the device: on a two-socket host a
+  // thread on the other socket queues every copy across the socket link (its runtime-internal staging too)
+  if (me->place.have_set && pthread_setaffinity_np(pthread_self(), sizeof(me->place.set), &me->place.set) == 0) {
+    std::lock_guard<std::mutex> lk(me->mu);
+    me->place.pinned = true;
+    format_cpulist(&me->place.set, me->place.cpus, sizeof(me->place.cpus));
+  }
+  { std::lock_guard<std::mutex> lk(me->mu); me->started = true; }
+  me->cv.notify_all();
   for (;;) {
     std::unique_lock<std::mutex> lk(me->mu);
     me->cv.wait(lk, [&] { return me->task != nullptr || me->quit; });
@@ -1029,9 +1152,14 @@ extern "C" int sadhip_pool_create(const int* devices, int n_devices, int max_w, 
       w->index = g; w->stride = n_devices;
       const int st = sadhip_ctx_create(devices[g], max_w, max_h, 1, &w->ctx);
       if (st != SADHIP_OK) { destroy_pool(p); return st; }     // detail already in g_err
+      w->place = find_placement(devices[g]);
       p->w.push_back(std::move(w));
     }
     for (auto& w : p->w) w->th = std::thread(pool_worker_main, w.get());
+    for (auto& w : p->w) {                                     // placement is settled when create returns (sadhip_pool_describe)
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return w->started; });
+    }
   } catch (const std::bad_alloc&) {
     destroy_pool(p);
     return fail(SADHIP_ERR_NOMEM, "pool allocation failed");
@@ -1054,6 +1182,21 @@ extern "C" int sadhip_pool_size(const sadhip_pool* pool, int* n_devices)
 {
   if (!pool || !n_devices) return fail(SADHIP_ERR_NULL, "pool or n_devices is NULL");
   *n_devices = (int)pool->w.size();
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_pool_describe(const sadhip_pool* pool, char* buf, int cap)
+{
+  if (!pool || !buf) return fail(SADHIP_ERR_NULL, "pool or buf is NULL");
+  if (cap < 1) return fail(SADHIP_ERR_ARG, "cap=%d", cap);
+  int at = 0;
+  buf[0] = 0;
+  for (const auto& w : pool->w) {
+    std::lock_guard<std::mutex> lk(w->mu);
+    if (at < cap)
+      at += snprintf(buf + at, (size_t)(cap - at), "entry=%d device=%d pci=%s numa_node=%d pinned=%d cpus=%s\n", w->index, w->place.device,
+                     w->place.pci[0] ? w->place.pci : "?", w->place.numa_node, (int)w->place.pinned, w->place.pinned ? w->place.cpus : "-");
+  }
   return SADHIP_OK;
 }
 

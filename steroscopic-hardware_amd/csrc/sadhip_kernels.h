@@ -1,6 +1,7 @@
 // sadhip_kernels.h -- launch interface between the C-ABI host code (sadhip.hip) and the
 // gfx950 kernels (kernels_generic.hip, kernels_fast.hip).  Internal; not installed.
 #pragma once
+#include "../../include/sadhip.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -35,13 +36,18 @@ struct Job {
 
 // Which kernel the calling thread launched last (every launch_* records it on success); the C ABI
 // reports it through sadhip_last_kernel_kind() so tests and the bench can assert which code ran.
-enum { KIND_NONE = -1, KIND_GENERIC = 0, KIND_COLWAVE = 1, KIND_MIRROR_SADC = 2, KIND_MIRROR_TESTPY = 3, KIND_MIRROR_VERILOG = 4 };
+enum { KIND_NONE = -1, KIND_GENERIC = 0, KIND_COLWAVE = 1, KIND_MIRROR_SADC = 2, KIND_MIRROR_TESTPY = 3, KIND_MIRROR_VERILOG = 4,
+       KIND_GENERIC_SLIDING = 5 };
 void note_launch(int kind);
 int last_launch_kind();
 
 // Generic kernel: any block / maxdisp / size.  One thread per output pixel, closed-form
 // restatement of sad.go:55-94 with u32 accumulators.  Always available.
 hipError_t launch_generic(const Job& j, hipStream_t s);
+// ... in its running-sum form (kernels_sliding.hip): O(1) work per (pixel, candidate) whatever BlockSize is.  launch_generic
+// routes a job there when a pixel's naive work, (2h+1)^2 * (D+1) byte differences, exceeds SADHIP_GENERIC_MAX_WORK.
+hipError_t launch_sliding(const Job& j, hipStream_t s);
+bool generic_uses_sliding(int block, int maxdisp);
 
 // Hardware-mirror golden models (mode 1: hardware/sad.c, mode 2: hardware/test.py, mode 3: the strip
 // search of hardware/compute_SAD.v); raw d output.

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     l = C.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(l, name), f"{name} not exported"
-    assert capi.lib().sadhip_abi_version() == capi.ABI_VERSION == 3
+    assert capi.lib().sadhip_abi_version() == capi.ABI_VERSION == 4
 
 
 def test_status_strings():
@@ -210,7 +210,12 @@ def test_whole_ui_parameter_grid_plans_on_the_fast_kernel():
         for block in range(3, 32, 2):
             for maxdisp in range(16, 257, 16):
                 assert capi.kernel_kind(w, h, block, maxdisp) == 1, (w, h, block, maxdisp)
-    assert capi.kernel_kind(1920, 1080, 33, 64) == 0             # BlockSize > 31: generic kernel
+    assert capi.kernel_kind(1920, 1080, 33, 64) == capi.KIND_GENERIC_SLIDING      # BlockSize > 31: generic kernel, running-sum form (33^2 * 65 > the work bound)
+    assert capi.kernel_kind(1920, 1080, 33, 16) == capi.KIND_GENERIC              # ... the naive form below it
+    for block, maxdisp in ((33, 64), (255, 1), (255, 4096), (9, 4096), (31, 67), (31, 68), (3, 4096), (1, 4096)):
+        b1 = 2 * (block // 2) + 1
+        want = capi.KIND_GENERIC_SLIDING if b1 * b1 * (maxdisp + 1) > capi.GENERIC_MAX_WORK else capi.KIND_GENERIC
+        assert capi.kernel_kind(64, 64, block, maxdisp, capi.FLAG_FORCE_GENERIC) == want, (block, maxdisp)
     assert capi.kernel_kind(100, 100, 9, 96) == 1                # frame narrower than D+2h+3: the unpacked variant
     assert all(not ps["packed"] for ps in capi.plan_describe(100, 100, 9, 96))
     assert capi.kernel_kind(100, 100, 3, 96) == 0                # ... which does not exist for BlockSize < 6

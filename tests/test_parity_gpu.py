@@ -16,6 +16,8 @@ from conftest import REAL_CASES, REAL_PAIRS, load_real_gray, load_real_pixels
 
 pytestmark = pytest.mark.gpu
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 BOTH = [0, capi.FLAG_FORCE_GENERIC]          # dispatcher's choice, and the generic kernel
 
 
@@ -324,13 +326,70 @@ def test_maximum_parameters():
         assert np.array_equal(g[3:5], oracle.disparity_literal(narrow_L, narrow_R, block, D, region=(0, 3, 700, 5))), block
     small_L, small_R = sha.synth.synth_pair(255, 96, 40)
     g = ctx.disparity(small_L, small_R, capi.MAX_BLOCK, 64)                                     # window 255 x 255 > the image
-    assert capi.last_kernel_kind() == capi.KIND_GENERIC
+    assert capi.last_kernel_kind() == capi.KIND_GENERIC_SLIDING                                 # 255^2 * 65 per pixel: the running-sum form
     assert np.array_equal(g, oracle.disparity_literal(small_L, small_R, capi.MAX_BLOCK, 64))
     for block, maxdisp, status in ((capi.MAX_BLOCK + 1, 64, capi.ERR_BLOCK), (9, capi.MAX_MAXDISP + 1, capi.ERR_MAXDISP)):
         with pytest.raises(capi.SadHipError) as e:
             ctx.disparity(small_L, small_R, block, maxdisp)
         assert e.value.status == status
     ctx.close()
+
+
+def test_generic_path_is_bounded_running_sum_kernel(ctx):
+    """the one-thread-per-pixel generic kernel is O(BlockSize^2 * D) per pixel and the ABI accepts
+    BlockSize up to 255 at any frame size.  Above SADHIP_GENERIC_MAX_WORK byte differences per pixel the generic path runs
+    its running-sum form (kernels_sliding.hip, kind 5): same function, O(D) per pixel.
+    (1) small frames, every kind of parameter that reaches it -- large odd / even blocks, windows larger than the frame,
+        D > w, regions, raw / scaled, a right image smaller than the left one -- against the literal oracle;
+    (2) against the naive generic kernel just below / above the bound (the two forms agree where both can run);
+    (3) 1920x1080, BlockSize 63, MaxDisparity 64: three oracle bands (literal restatement) and a wall-time bound -- the
+        naive kernel needs ~0.2 s for this frame, the call must finish in well under that."""
+    import time
+    rng = np.random.default_rng(63)
+    for (w, h, block, D) in ((96, 40, 255, 64), (200, 70, 63, 64), (333, 45, 33, 64), (150, 90, 101, 16), (64, 64, 32, 100),
+                             (40, 30, 47, 300), (700, 24, 35, 128), (130, 130, 129, 9), (517, 33, 31, 300), (5, 4, 255, 4096)):
+        L = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        R = np.roll(L, -min(D, 11), axis=1) ^ (rng.integers(0, 8, (h, w), dtype=np.uint8) == 0).astype(np.uint8)
+        assert capi.kernel_kind(w, h, block, D, capi.FLAG_FORCE_GENERIC) == capi.KIND_GENERIC_SLIDING, (w, h, block, D)
+        raw = D <= 255
+        got = ctx.disparity(L, R, block, D, capi.FLAG_FORCE_GENERIC | (capi.FLAG_RAW if raw else 0))
+        assert capi.last_kernel_kind() == capi.KIND_GENERIC_SLIDING
+        assert np.array_equal(got, oracle.disparity_literal(L, R, block, D, raw=raw)), (w, h, block, D)
+        if w > 8 and h > 8:
+            reg = (w // 5, 2, w - 3, h - 1)
+            assert np.array_equal(ctx.disparity_region(L, R, block, D, reg, capi.FLAG_FORCE_GENERIC),
+                                  oracle.disparity_literal(L, R, block, D, region=reg)), (w, h, block, D, "region")
+            Rs = np.ascontiguousarray(R[: h - 7, : w - 9])                        # smaller right image: dropped terms
+            assert np.array_equal(ctx.disparity_lr(L, Rs, block, D), oracle.disparity_literal_lr(L, Rs, block, D)), (w, h, block, D, "lr")
+    flat = np.full((50, 120), 9, np.uint8)
+    assert not ctx.disparity(flat, flat.copy(), 63, 64).any()                     # every candidate ties: d = 0
+    # the two generic forms agree either side of the bound: 31^2 * 68 = 65 348 (naive), 31^2 * 69 = 66 309 (running sums)
+    L, R = sha.synth.synth_pair(31, 400, 60)
+    a = ctx.disparity(L, R, 31, 67, capi.FLAG_FORCE_GENERIC | capi.FLAG_RAW); ka = capi.last_kernel_kind()
+    b = ctx.disparity(L, R, 31, 68, capi.FLAG_FORCE_GENERIC | capi.FLAG_RAW); kb = capi.last_kernel_kind()
+    assert (ka, kb) == (capi.KIND_GENERIC, capi.KIND_GENERIC_SLIDING)
+    assert np.array_equal(a, oracle.disparity_closed(L, R, 31, 67, raw=True)) and np.array_equal(b, oracle.disparity_closed(L, R, 31, 68, raw=True))
+    # a device-resident batch through the same form
+    import torch
+    Ls, Rs = sha.synth.synth_batch_torch([70, 71, 72], 600, 80, "cuda:0")
+    out = torch.full_like(Ls, 0xCD)
+    ctx.disparity_dev(Ls, Rs, out, 41, 64)
+    torch.cuda.synchronize()
+    assert capi.last_kernel_kind() == capi.KIND_GENERIC_SLIDING
+    for i in range(3):
+        Li, Ri = sha.synth.synth_pair(70 + i, 600, 80)
+        assert np.array_equal(out[i].cpu().numpy(), oracle.disparity_closed(Li, Ri, 41, 64))
+    # (3) the full-size case with a wall-time bound
+    L, R = sha.synth.synth_pair(63, 1920, 1080)
+    ctx.disparity(L, R, 63, 64)                                                   # warm-up (module load, scratch)
+    t0 = time.perf_counter()
+    got = ctx.disparity(L, R, 63, 64)
+    wall = time.perf_counter() - t0
+    k_ms, _ = ctx.last_timing()
+    assert capi.last_kernel_kind() == capi.KIND_GENERIC_SLIDING
+    for y0 in (0, 537, 1076):
+        assert np.array_equal(got[y0:y0 + 4], oracle.disparity_rows_mt(L, R, 63, 64, y0, y0 + 4, min(16, os.cpu_count() or 1))), y0
+    assert wall < 0.1 and k_ms < 60, (wall, k_ms)                                 # naive: 63^2 * 65 * 2.07e6 = 5.3e11 byte differences, ~0.2 s
 
 
 def test_random_parameter_sweep(ctx):
@@ -710,6 +769,111 @@ def test_page_locked_host_memory_paths(ctx):
     assert l.sadhip_host_alloc(0, ctypes.byref(p)) == capi.ERR_ARG
     assert l.sadhip_host_alloc(4096, ctypes.byref(p)) == capi.OK and p.value
     assert l.sadhip_host_free(p) == capi.OK and l.sadhip_host_free(p) == capi.ERR_ARG
+
+
+def test_page_locked_batch_slot_reuse_and_failure_drains_the_streams(tmp_path):
+    """the page-locked batch pipeline has 4 slots of 8 frames; a slot is reused from the fifth group on (wait for
+    its download, read its kernel events, make the upload stream wait) -- only batches of more than 32 frames get there.
+    (1) 43 distinct small frames (5 groups + 3 frames) in page-locked memory, every frame against the oracle, twice (the
+    second call starts on used slots).  (2) In the diagnostics build a failure is injected after the kernel of group 4
+    (the first reused slot) has been queued: the call must return the error with NOTHING in flight -- outputs overwritten
+    right after the return stay as written -- and the same context must run the whole batch correctly afterwards."""
+    n, w, h, B, D = 43, 64, 48, 9, 32
+    frames = [sha.synth.synth_pair(5000 + i, w, h) for i in range(n)]
+    exp = [oracle.disparity_closed(L, R, B, D) for L, R in frames]
+    with capi.Context(0, w, h, 1) as c, capi.HostBuffer(3 * n * w * h) as hb:
+        blk = hb.view((3, n, h, w))
+        for i, (L, R) in enumerate(frames):
+            blk[0, i] = L; blk[1, i] = R
+        for rep in range(2):
+            blk[2] = 0xEE
+            outs = c.disparity_batch([blk[0, i] for i in range(n)], [blk[1, i] for i in range(n)], B, D, outs=[blk[2, i] for i in range(n)])
+            for i in range(n):
+                assert np.array_equal(outs[i], exp[i]), (rep, i)
+    import subprocess, sys, textwrap
+    script = textwrap.dedent(f"""
+        import os, sys, time
+        sys.path[:0] = [{REPO!r}, {os.path.join(REPO, "oracle")!r}]
+        import numpy as np
+        import steroscopic_hardware_amd as sha, oracle
+        from steroscopic_hardware_amd import capi
+        capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libsadhip_tune.so")
+        n, w, h, B, D = {n}, {w}, {h}, {B}, {D}
+        frames = [sha.synth.synth_pair(5000 + i, w, h) for i in range(n)]
+        with capi.Context(0, w, h, 1) as c, capi.HostBuffer(3 * n * w * h) as hb:
+            blk = hb.view((3, n, h, w))
+            for i, (L, R) in enumerate(frames):
+                blk[0, i] = L; blk[1, i] = R
+            blk[2] = 0xEE
+            args = ([blk[0, i] for i in range(n)], [blk[1, i] for i in range(n)], B, D)
+            os.environ["SADHIP_TUNE_FAIL_GROUP"] = "4"
+            try:
+                c.disparity_batch(*args, outs=[blk[2, i] for i in range(n)])
+                print("NOERROR"); sys.exit(1)
+            except capi.SadHipError as e:
+                assert e.status == capi.ERR_HIP and "injected failure" in str(e), e
+            blk[2] = 0x5A                                    # anything still in flight would overwrite this
+            blk[0] ^= 0xFF                                   # ... or read this
+            time.sleep(0.2)
+            assert (blk[2] == 0x5A).all(), "a download landed after the failing call returned"
+            blk[0] ^= 0xFF
+            del os.environ["SADHIP_TUNE_FAIL_GROUP"]
+            outs = c.disparity_batch(*args, outs=[blk[2, i] for i in range(n)])
+            for i, (L, R) in enumerate(frames):
+                assert np.array_equal(outs[i], oracle.disparity_closed(L, R, B, D)), i
+        print("DRAINED-OK")
+    """)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "DRAINED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_host_register_refuses_overlapping_ranges():
+    """the registry of page-locked ranges is sorted and DISJOINT (is_pinned looks at one predecessor, removal goes
+    by start address): a registration that overlaps a known range -- a sub-range of a sadhip_host_alloc block, a sub- or
+    super-range of an earlier registration -- is SADHIP_ERR_ARG and registers nothing."""
+    import ctypes
+    l = capi.lib()
+    with capi.HostBuffer(1 << 20) as hb:
+        base = hb.view((1 << 20,)).ctypes.data
+        for off, size in ((0, 4096), (8192, 4096), ((1 << 20) - 4096, 4096)):
+            assert l.sadhip_host_register(ctypes.c_void_p(base + off), size) == capi.ERR_ARG, (off, size)
+    a = np.zeros(1 << 20, np.uint8)
+    p = a.ctypes.data
+    assert l.sadhip_host_register(ctypes.c_void_p(p + 65536), 262144) == capi.OK
+    for off, size in ((65536, 262144), (65536 + 4096, 4096), (0, 131072), (300000, 131072), (0, 1 << 20)):
+        assert l.sadhip_host_register(ctypes.c_void_p(p + off), size) == capi.ERR_ARG, (off, size)
+    assert l.sadhip_host_register(ctypes.c_void_p(p), 65536) == capi.OK                   # adjacent, not overlapping
+    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 4096)) == capi.ERR_ARG             # not the start of a range
+    assert l.sadhip_host_unregister(ctypes.c_void_p(p)) == capi.OK
+    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 65536)) == capi.OK
+    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 65536)) == capi.ERR_ARG
+
+
+def test_pool_workers_are_pinned_next_to_their_device():
+    """sadhip_pool_describe (ABI 4): every worker thread of the pool is pinned at creation to the CPUs of its device's NUMA
+    node (PCI bus id -> sysfs local_cpulist, cut down to this process's affinity mask); best effort -- asserted as far as
+    the box lets it be read: bus id, node, and when pinned a CPU list inside the process's own mask."""
+    import re
+    with capi.Pool([0, 0], 640, 480) as pool:
+        d = pool.describe()
+        assert [e["entry"] for e in d] == [0, 1] and all(e["device"] == 0 for e in d)
+        for e in d:
+            assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-9a-f]", e["pci"]) or e["pci"] == "?", e
+            assert e["pinned"] in (0, 1) and isinstance(e["numa_node"], int)
+            sysfs = f"/sys/bus/pci/devices/{e['pci']}/local_cpulist"
+            if e["pinned"]:
+                cpus = set()
+                for part in e["cpus"].split(","):
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+                assert cpus and cpus <= set(os.sched_getaffinity(0)), e
+                assert os.path.exists(sysfs)
+            else:
+                assert e["cpus"] == "-"
+        # and the pool still computes: two contexts on the one device, frames round-robin
+        L, R = sha.synth.synth_pair(77, 320, 100)
+        outs = pool.batch([L] * 5, [R] * 5, 9, 32)
+        assert all(np.array_equal(o, oracle.disparity_closed(L, R, 9, 32)) for o in outs)
 
 
 def test_device_resident_batch(ctx):
