@@ -88,8 +88,9 @@ __global__ void __launch_bounds__(SL_NT) k_disparity_sliding(SlArgs a)
 #pragma unroll
     for (int e = 0; e < SL_E; ++e) C[e] = 0u;
     for (int r = ys - hs; r < ye + hs; ++r) {                                       // row r enters the window, row r - B1 leaves it
+      const bool leaving = r - B1 >= ys - hs;                                       // (only rows this strip has added: the sums start at row ys - hs)
 #pragma unroll
-      for (int e = 0; e < SL_E; ++e) C[e] += diff(r, col[e], d) - diff(r - B1, col[e], d);
+      for (int e = 0; e < SL_E; ++e) C[e] += diff(r, col[e], d) - (leaving ? diff(r - B1, col[e], d) : 0u);
       const int y = r - hs;                                                         // the output row whose window is now complete
       if (y < ys) continue;                                                         // (uniform: warm-up rows)
       const unsigned pair = C[0] + C[1];

@@ -468,7 +468,10 @@ def test_u16_ring_chunks_of_four_and_mixed_chunk_plans(ctx):
     """Round 4: the unpacked kernels (BlockSize >= 16) for 16k+1 candidates with k odd.  MaxDisparity 16 plans as 4 waves x 4
     candidates + 1 on the u16 ring (8-byte operand reads); 48 / 80 / 112 as MIXED workgroups -- 4 / 8 / 12 waves of 8
     candidates followed by 4 waves of 4, + 1 -- and 176 / 208 / 240 with such a pass after a full pass of 128.  Random,
-    shifted, extreme (largest SADs) and flat frames, widths of one to three tiles and every w mod 8, against the oracle."""
+    shifted, extreme (largest SADs) and flat frames, widths of one to three tiles and every w mod 8: every frame against
+    the generic path on the device (an independent implementation, itself held to the oracle by its own tests) and rows
+    of every frame against the oracle itself."""
+    import torch
     rng = np.random.default_rng(44)
     for block, w in ((16, 437), (17, 700), (19, 1030), (23, 517), (27, 941), (31, 1203)):
         hh = block // 2
@@ -482,12 +485,19 @@ def test_u16_ring_chunks_of_four_and_mixed_chunk_plans(ctx):
             R[1] = np.roll(L[1], -min(D, 29), axis=1)
             L[2] = 255; R[2] = 0; R[2][:, w // 3:] = 255; R[2][:, 2 * w // 3:] = 0
             L[3] = 91; R[3] = 91
-            for i in range(4):
-                got = ctx.disparity(L[i], R[i], block, D, capi.FLAG_RAW)
-                assert capi.last_kernel_kind() == capi.KIND_COLWAVE
-                assert np.array_equal(got, _expect(L[i], R[i], block, D, raw=True)), (block, w, D, i)
+            Ls, Rs = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+            a, b = torch.full_like(Ls, 0xCD), torch.full_like(Ls, 0xEE)
+            ctx.disparity_dev(Ls, Rs, a, block, D, capi.FLAG_RAW)
+            assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+            ctx.disparity_dev(Ls, Rs, b, block, D, capi.FLAG_RAW | capi.FLAG_FORCE_GENERIC)
+            torch.cuda.synchronize()
+            got = a.cpu().numpy()
+            assert np.array_equal(got, b.cpu().numpy()), (block, w, D)
+            for i in range(4):                                   # two rows of every frame against the oracle, through the host path
+                one = ctx.disparity_region(L[i], R[i], block, D, (0, hh + 3, w, hh + 5), capi.FLAG_RAW)
+                assert np.array_equal(one, got[i][hh + 3:hh + 5]), (block, w, D, i)
+                assert np.array_equal(one, oracle.disparity_closed(L[i], R[i], block, D, region=(0, hh + 3, w, hh + 5), raw=True)), (block, w, D, i)
     # and as a device-resident batch at 1080p width (several tiles, the batched strip geometry), against the generic kernel
-    import torch
     for block, D in ((16, 48), (21, 80), (31, 112), (16, 16)):
         g = torch.Generator(device="cuda").manual_seed(block * 1000 + D)
         Ls = torch.randint(0, 256, (6, 70, 1920), dtype=torch.uint8, device="cuda", generator=g)
@@ -547,7 +557,7 @@ def test_large_blocks_two_lane_halo(ctx):
     L, R = sha.synth.synth_pair(55, 1100, 90)                   # several tiles (480 output columns each) and strips
     for block in (19, 31):
         assert np.array_equal(ctx.disparity(L, R, block, 64), ctx.disparity(L, R, block, 64, capi.FLAG_FORCE_GENERIC))
-    assert capi.kernel_kind(640, 480, 33, 64) == 0                # beyond 31: the generic kernel
+    assert capi.kernel_kind(640, 480, 33, 64) == capi.KIND_GENERIC_SLIDING   # beyond 31: the generic path (running-sum form at this size)
 
 
 def test_tall_frame_many_strips_and_tiles(ctx):

@@ -23,7 +23,13 @@ def run(ncases=300, seed=0):
         if rng.random() < 0.3:                                      # round 3's new forms: BlockSize 15 (two-form, h = 7), 16 / 17 (suffix-free window sums), 9
             block = int(rng.choice([9, 14, 15, 15, 16, 16, 17]))
             w = int(rng.choice([w, rng.integers(240, 800), rng.integers(800, 4000)]))
+        r4 = rng.random() < 0.2                                     # round 4: u16 ring with chunks of 4, mixed-chunk workgroups (BlockSize >= 16, D = 16 mod 32)
+        if r4:
+            block = int(rng.integers(16, 32))
+            w = int(rng.choice([rng.integers(300, 700), rng.integers(700, 2100)]))
         D = int(rng.choice([rng.integers(1, 20), rng.choice([16, 32, 48, 64, 96, 128, 160, 192, 256]), rng.integers(20, 400)]))
+        if r4:
+            D = int(rng.choice([16, 48, 80, 112, 144, 176, 208, 240, 47, 79]))
         style = int(rng.integers(0, 6))
         if style == 0:
             L = rng.integers(0, 256, (h, w), dtype=np.uint8); R = rng.integers(0, 256, (h, w), dtype=np.uint8)

@@ -33,7 +33,7 @@ int main() {
     ks[k]<<<p.multiProcessorCount * 16, 256>>>(d); (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0); ks[k]<<<p.multiProcessorCount * 16, 256>>>(d); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-    double inst = 4096.0 * 8 * 16 * 4;   // per SIMD: 16 blocks x 4 waves / 4 SIMDs = 16 waves
+    double inst = 4096.0 * 8 * 16;       // per SIMD: 16 blocks x 4 waves / 4 SIMDs = 16 waves of 4096 x 8 instructions (rounds 1-3 printed a quarter of this: a stray x 4)
     printf("%-20s %.3f ms  %.2f cycles per wave-instruction per SIMD\n", nm[k], ms, ms * 1e-3 * 2.4e9 / inst);
   }
   return 0;
