@@ -24,7 +24,7 @@ int env_int(const char* name, int dflt)
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
                                         "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE",
-                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX"};
+                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX", "SADHIP_TUNE_TAILPCT"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -204,7 +204,11 @@ long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_ro
     if ((rows + th - 1) / th != ns) continue;                   // this strip height gives fewer strips: counted there
     const long w = base * ns, k = (w + cus - 1) / cus;
     const double whole = (double)((k + per_cu - 1) / per_cu);   // rounds on the busiest CU
-    const double t = (k <= per_cu ? 0.27 + 0.73 * (double)k / per_cu : 0.5 * ((double)w / slots + whole)) + 0.15;
+    double t = (k <= per_cu ? 0.27 + 0.73 * (double)k / per_cu : 0.5 * ((double)w / slots + whole)) + 0.15;
+    // tuning aid (round 4 A/B, tools/ab_strips4.sh): several rounds as ideal rounds + a tail of `SADHIP_TUNE_TAILPCT` % of one
+    // workgroup's duration -- workgroups are handed out as slots free up, the busiest-CU round count overstates the wait
+    const int tail_pct = env_int("SADHIP_TUNE_TAILPCT", 0);
+    if (tail_pct > 0 && k > per_cu) t = (double)w / slots + tail_pct / 100.0;
     const double cost = t * (double)(th + h2 + 4);
     if (cost < best * 0.999) { best = cost; best_ns = ns; }     // ties: fewer strips
   }

@@ -302,7 +302,7 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
   const size_t per_frame = (size_t)kw * rows * sizeof(unsigned);
   const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)j.n, ((size_t)256 << 20) / per_frame));
   unsigned* keys = nullptr;
-  hipError_t e = hipMallocAsync((void**)&keys, per_frame * chunk, s);
+  hipError_t e = scratch_alloc((void**)&keys, per_frame * chunk, s);
   if (e != hipSuccess) return e;
   for (int f0 = 0; f0 < j.n && e == hipSuccess; f0 += chunk) {
     Job jj = j;
@@ -317,7 +317,7 @@ hipError_t launch_fast(const Job& j, hipStream_t s)
                 passes[k].pl.p, passes[k].pl.nd, passes[k].pl.nw, (int)passes[k].pl.pk, (int)passes[k].pl.extra, hipGetErrorString(e));
     }
   }
-  const hipError_t ef = hipFreeAsync(keys, s);
+  const hipError_t ef = scratch_free(keys, s);
   if (e == hipSuccess && ef == hipSuccess) note_launch(KIND_COLWAVE);
   return e != hipSuccess ? e : ef;
 }

@@ -9,12 +9,53 @@
 // :205-244:
 //     dmax(x) = min(D, max(0, x - hs)),   window clipped to the image, L and R aligned.
 #include "sadhip_kernels.h"
+#include <mutex>
 
 namespace sadhip {
 
 static thread_local int g_last_kind = KIND_NONE;
 void note_launch(int kind) { g_last_kind = kind; }
 int last_launch_kind() { return g_last_kind; }
+
+// ---- stream-ordered scratch from the library's own pool (sadhip_kernels.h) ---------------------------------------
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_pool_mu;
+hipMemPool_t g_pools[kMaxDevices] = {};
+bool g_pool_tried[kMaxDevices] = {};
+
+hipMemPool_t scratch_pool()
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (!g_pool_tried[dev]) {
+    g_pool_tried[dev] = true;
+    hipMemPoolProps props{};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
+      unsigned long long keep = 1ull << 30;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      g_pools[dev] = pool;
+    } else {
+      (void)hipGetLastError();                               // no pool: the device's default one serves (correct, maybe slower)
+    }
+  }
+  return g_pools[dev];
+}
+}  // namespace
+
+hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s)
+{
+  if (hipMemPool_t pool = scratch_pool()) return hipMallocFromPoolAsync(p, bytes, pool, s);
+  return hipMallocAsync(p, bytes, s);
+}
+
+hipError_t scratch_free(void* p, hipStream_t s) { return hipFreeAsync(p, s); }
 
 __global__ void __launch_bounds__(256)
 k_disparity_generic(Job j)

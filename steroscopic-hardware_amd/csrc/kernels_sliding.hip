@@ -149,7 +149,7 @@ hipError_t launch_sliding(const Job& j, hipStream_t s)
   nstrips = (rows + a.th - 1) / a.th;
   a.kw = kw; a.krows = rows;
   unsigned long long* keys = nullptr;
-  hipError_t e = hipMallocAsync((void**)&keys, per_frame * (size_t)chunk, s);
+  hipError_t e = scratch_alloc((void**)&keys, per_frame * (size_t)chunk, s);
   if (e != hipSuccess) return e;
   a.keys = keys;
   for (int f0 = 0; f0 < j.n && e == hipSuccess; f0 += chunk) {
@@ -161,7 +161,7 @@ hipError_t launch_sliding(const Job& j, hipStream_t s)
     hipLaunchKernelGGL(k_disparity_sliding, dim3((unsigned)tiles, (unsigned)nstrips, (unsigned)a.j.n), dim3(SL_NT), 0, s, a);
     e = hipGetLastError();
   }
-  const hipError_t ef = hipFreeAsync(keys, s);
+  const hipError_t ef = scratch_free(keys, s);
   if (e == hipSuccess && ef == hipSuccess) note_launch(KIND_GENERIC_SLIDING);
   return e != hipSuccess ? e : ef;
 }

@@ -41,6 +41,14 @@ enum { KIND_NONE = -1, KIND_GENERIC = 0, KIND_COLWAVE = 1, KIND_MIRROR_SADC = 2,
 void note_launch(int kind);
 int last_launch_kind();
 
+// Stream-ordered scratch (the u32 / u64 key per pixel that travels between the passes of a multi-pass job, the running-sum
+// kernel's keys): allocated from the library's OWN memory pool of the current device, whose release threshold keeps up to
+// 1 GiB cached.  From the device's default pool (release threshold 0) every stream synchronise hands unused memory back to
+// the driver and the next call pays for a fresh 256 MB allocation: on some boxes that was 3 ms per call (MaxDisparity 192 with
+// BlockSize 16: 152 us per pair instead of 105, tools/ubench/malloc_async.hip).  The host application's pools are not touched.
+hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s);
+hipError_t scratch_free(void* p, hipStream_t s);
+
 // Generic kernel: any block / maxdisp / size.  One thread per output pixel, closed-form
 // restatement of sad.go:55-94 with u32 accumulators.  Always available.
 hipError_t launch_generic(const Job& j, hipStream_t s);

@@ -4,9 +4,10 @@
 # tools/summarize_cfg.py into profiles/.
 #   tools/profile_cfg.sh <tag> W H BLOCK MAXDISP NFRAMES
 # Output: gpurun_out/prof_<tag>/{trace,pmc_sq,pmc_fetch,pmc_write}/
-# The counter passes sample the disparity kernels ONLY (--kernel-include-regex): bench_cfg.py builds its frames with
-# ~40 torch elementwise launches per pair, and counter collection over all of them is what aborted at 1024 resident
-# pairs in round 2 (PMC_FILTER= (empty) rebuilds that unfiltered run for the record).
+# The counter passes sample the disparity kernels ONLY (--kernel-include-regex, always): bench_cfg.py builds its frames
+# with ~40 torch elementwise launches per pair, and counter collection over all of them is what crashed the profiled
+# process at 1024 resident pairs in rounds 2 and 3 (a host-side SIGSEGV inside the profiler's dispatch interception,
+# DESIGN.md section 6; profiles/r03_pmc_unfiltered_1024pairs_FAIL.log).  There is no switch to run unfiltered.
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -14,9 +15,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-KFILTER=${PMC_FILTER-k_colwave|k_disparity|k_gray|k_sad_windows}
-FARGS=()
-[ -n "$KFILTER" ] && FARGS=(--kernel-include-regex "$KFILTER")
+FARGS=(--kernel-include-regex "k_colwave|k_disparity|k_gray|k_sad_windows")
 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/trace.log 2>&1
 echo "[$TAG] trace exit=$? $(tail -1 $OUT/trace.log)"
 timeout -k 10 420 rocprofv3 --kernel-trace "${FARGS[@]}" --pmc ${PMC_SQ:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES} GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $ROOT/tools/bench_cfg.py "$@" > $OUT/pmc_sq.log 2>&1

@@ -176,7 +176,7 @@ def main():
     TR = int(a.variant[6]) if len(a.variant) > 6 else 0
     ensure_asm(a.asm, a.defs)
     asm = open(a.asm).read()
-    sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb{TR}EEEvNS0_6CwArgsE"   # k_colwave<P, ND, H, PK, WB, W16, TR>
+    sym = f"_ZN6sadhip12_GLOBAL__N_19k_colwaveILi{P}ELi{ND}ELi{H}ELb{PK}ELi{WB}ELb{W16}ELb{TR}ELb0EEEvNS0_6CwArgsE"   # k_colwave<P, ND, H, PK, WB, W16, TR, MIX = false>
     blocks = analyse(kernel_body(asm, sym, 3 if TR else 1))
     main_ins, xtra_ins = [], []
     # the extra-candidate path = the blocks from the kernel's SADHIP_XTRA_BEGIN marker to its SADHIP_XTRA_END
