@@ -183,6 +183,33 @@ def _host_legs(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf):
     frame = W * H
     ref = out[:nf].cpu().numpy()                                  # the device-resident results of the timed launches
     legs = {}
+    # the thread that allocates (first-touches) the page-locked frames and makes the calls runs on the CPUs next to the
+    # device (sadhip_device_describe): on a two-socket box whose GPU hangs on the other node every copy would cross the
+    # socket link otherwise (measured: one synchronous call 0.44 ms instead of 0.21, host-fed 10 900 pairs/s instead of 11 500)
+    place, old_aff = None, None
+    try:
+        place = capi.device_describe(local)
+        if place["cpus"]:
+            old_aff = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, place["cpus"])
+    except (OSError, capi.SadHipError, AttributeError, KeyError, ValueError):
+        old_aff = None
+    try:
+        legs = _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, ref)
+    finally:
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
+    if place is not None:
+        legs["host_placement"] = {"pci": place["pci"], "numa_node": place["numa_node"], "host_thread_pinned_to_device_cpus": old_aff is not None,
+                                  "cpus": len(place["cpus"])}
+    return legs
+
+
+def _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, ref):
+    import numpy as np
+    capi = sha.capi
+    frame = W * H
+    legs = {}
     with capi.HostBuffer(3 * nf * frame) as hb:
         blk = hb.view((3, nf, H, W))
         blk[0] = Ls[:nf].cpu().numpy(); blk[1] = Rs[:nf].cpu().numpy()

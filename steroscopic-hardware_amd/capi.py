@@ -76,6 +76,7 @@ SYMBOLS = {
                                        C.POINTER(C.c_void_p), C.c_int]),
     "sadhip_pool_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sadhip_pool_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "sadhip_device_describe": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
 }
 
 _LIB = None
@@ -151,6 +152,20 @@ def device_count():
     n = C.c_int(0)
     _check(lib().sadhip_device_count(C.byref(n)))
     return n.value
+
+
+def device_describe(device=0):
+    """Where a device hangs on the host (sadhip_device_describe): dict device, pci, numa_node, cpus (a set of CPU numbers:
+    the device's local CPUs within this process's affinity mask; empty when unknown)."""
+    buf = C.create_string_buffer(1024)
+    _check(lib().sadhip_device_describe(device, buf, len(buf)))
+    d = dict(f.split("=", 1) for f in buf.value.decode().split())
+    cpus = set()
+    if d.get("cpus", "-") != "-":
+        for part in d["cpus"].split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return {"device": int(d["device"]), "pci": d["pci"], "numa_node": int(d["numa_node"]), "cpus": cpus}
 
 
 def kernel_kind(w, h, block, maxdisp, flags=0):

@@ -1185,6 +1185,21 @@ extern "C" int sadhip_pool_size(const sadhip_pool* pool, int* n_devices)
   return SADHIP_OK;
 }
 
+extern "C" int sadhip_device_describe(int device, char* buf, int cap)
+{
+  if (!buf) return fail(SADHIP_ERR_NULL, "buf is NULL");
+  if (cap < 1) return fail(SADHIP_ERR_ARG, "cap=%d", cap);
+  buf[0] = 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(SADHIP_ERR_NO_DEVICE, "no HIP device"); }
+  if (device < 0 || device >= n) return fail(SADHIP_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
+  Placement pl = find_placement(device);
+  char cpus[256] = "-";
+  if (pl.have_set) format_cpulist(&pl.set, cpus, sizeof(cpus));
+  snprintf(buf, (size_t)cap, "device=%d pci=%s numa_node=%d cpus=%s\n", device, pl.pci[0] ? pl.pci : "?", pl.numa_node, cpus);
+  return SADHIP_OK;
+}
+
 extern "C" int sadhip_pool_describe(const sadhip_pool* pool, char* buf, int cap)
 {
   if (!pool || !buf) return fail(SADHIP_ERR_NULL, "pool or buf is NULL");

@@ -880,6 +880,12 @@ def test_pool_workers_are_pinned_next_to_their_device():
                 assert os.path.exists(sysfs)
             else:
                 assert e["cpus"] == "-"
+        one = capi.device_describe(0)                            # the same lookup for a host that drives one context itself
+        assert one["device"] == 0 and one["pci"] == d[0]["pci"] and one["numa_node"] == d[0]["numa_node"]
+        assert one["cpus"] <= set(os.sched_getaffinity(0)) and (bool(one["cpus"]) == bool(d[0]["pinned"]))
+        with pytest.raises(capi.SadHipError) as ei:
+            capi.device_describe(99)
+        assert ei.value.status == capi.ERR_NO_DEVICE
         # and the pool still computes: two contexts on the one device, frames round-robin
         L, R = sha.synth.synth_pair(77, 320, 100)
         outs = pool.batch([L] * 5, [R] * 5, 9, 32)
