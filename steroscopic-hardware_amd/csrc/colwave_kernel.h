@@ -57,8 +57,9 @@ namespace {
 struct CwArgs {
   Job j;
   int nw;          // waves per workgroup (disparity chunks), 4..16
-  int nwa;         // waves [0, nwa) own ND candidates each; mixed-chunk kernels (k_colwave<..., MIX>): waves [nwa, nw) own ND/2 each.  nwa == nw otherwise
-  int slots;       // candidates of the pass without the odd one: nwa*ND + (nw - nwa)*ND/2
+  int nwa;         // waves [0, nwa) own ND candidates each; mixed-chunk kernels (k_colwave<..., MIX>): waves [nwa, nw) own NDB each
+                   // (MixChunk: ND/2 unpacked, ND-4 packed).  nwa == nw otherwise
+  int slots;       // candidates of the pass without the odd one: nwa*ND + (nw - nwa)*NDB
   int xw;          // wave that also owns candidate `slots` (the 16k+1-th), or -1
   int ksh;         // bits of the disparity field of a key (unpacked: 2^ksh > maxdisp; packed: 16)
   int pixshift;    // left shift applied to pixels landing in LDS (unpacked: ksh; packed: 0)
@@ -692,9 +693,9 @@ struct Cw {                                         // P columns per lane: 4 (pa
   }
 
   // wv0 / dcl0: first wave of this wave's group and the group's first candidate within the pass (0, 0 unless the kernel
-  // mixes two chunk sizes: there the waves [nwa, nw) run Cw<P, ND/2, ...>::run(a, nwa, nwa*ND) on the SAME ring, row
+  // mixes two chunk sizes: there the waves [nwa, nw) run Cw<P, NDB, ...>::run(a, nwa, nwa*ND) on the SAME ring, row
   // buffers and barriers -- every quantity of the LDS layout below depends on a.slots / a.nw, none on ND)
-  static __device__ void run(const CwArgs& a, const int wv0 = 0, const int dcl0 = 0)
+  static __device__ __forceinline__ void run(const CwArgs& a, const int wv0 = 0, const int dcl0 = 0)
   {
     extern __shared__ __attribute__((aligned(16))) unsigned smem[];
     const Job& j = a.j;
@@ -1089,25 +1090,21 @@ struct Cw {                                         // P columns per lane: 4 (pa
 };
 
 
-// WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
-// TR: the kernel holds both forms of the row loop (Cw::TR3): the triple-column form for the workgroups whose tile does
-// not hold the image's last two columns, the plain form for the others.
-// MIX (round 4): a workgroup of nwa waves with ND candidates each followed by nw - nwa waves with ND/2 each, for disparity
-// ranges that are no multiple of ND per SIMD -- 49 = 4*8 + 4*4 + 1, 81 = 8*8 + 4*4 + 1, 113 = 12*8 + 4*4 + 1 (the UI's
-// MaxDisparity 48, 80, 112).  The dispatcher places the waves of a workgroup on the four SIMDs round-robin
+// MIX (round 4): a workgroup of nwa waves with ND candidates each followed by nw - nwa waves with a smaller chunk NDB, for
+// disparity ranges that are no multiple of ND per SIMD -- unpacked on the u16 ring 8 + 4: 49 = 4*8 + 4*4 + 1, 81 = 8*8 + 4*4 + 1,
+// 113 = 12*8 + 4*4 + 1 (the UI's MaxDisparity 48, 80, 112); packed P = 4 (ND, ND - 4): 81 = 4*12 + 4*8 + 1, 113 = 4*16 + 4*12 + 1,
+// 145 = 4*20 + 4*16 + 1, 177 = 4*24 + 4*20 + 1.  The dispatcher places the waves of a workgroup on the four SIMDs round-robin
 // (tools/ubench/simd_map.hip), so with nwa and nw - nwa multiples of 4 every SIMD gets the same mix and no SIMD paces
 // the row barrier; uniform plans of these ranges either leave a quarter of the chip idle (7 waves of 8) or need 12-wave
 // workgroups of 4 (measured 10 % slower than 7 x 8).  Both groups run on one ring, one pair of row buffers and the same
 // barriers; the groups differ only in their column-sum registers and operand offsets.
-template <int P, int ND, int H, bool PK, int WB, bool W16, bool TR = false, bool MIX = false>
-__global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
+template <int P, int ND, bool PK> struct MixChunk { static constexpr int NDB = PK ? ND - 4 : ND / 2; };
+
+// One wave group of a kernel: picks the form (TR: per workgroup, see k_colwave) and runs it.
+template <int P, int ND, int H, bool PK, bool W16, bool TR>
+__device__ __forceinline__ void run_group(const CwArgs& a, int wv0, int dcl0)
 {
-  if constexpr (MIX) {
-    static_assert(!TR && W16 && !PK && ND == 8, "mixed chunks: unpacked kernels on the u16 ring, chunks of 8 and 4");
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wv < a.nwa) Cw<P, ND, H, PK, W16, false>::run(a);
-    else Cw<P, ND / 2, H, PK, W16, false>::run(a, a.nwa, a.nwa * ND);
-  } else if constexpr (TR) {
+  if constexpr (TR) {
     // per workgroup: the tile with the image's last two columns runs the plain form (Cw::TR3), and for h = 6, 7 so does
     // every tile with an output pixel x whose window starts left of a candidate of this pass (x - h < d: the plain form
     // masks those keys; the triple form carries no masks)
@@ -1119,9 +1116,26 @@ __global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
       const int ox0 = max(tile == 0 ? a.j.x0 : tx + K::OL, a.j.x0);
       triple = triple && !(max(ox0, 0) - H < min(a.dbase + a.slots, a.j.maxdisp));
     }
-    if (triple) K::run(a); else Cw<P, ND, H, PK, W16, false>::run(a);
+    if (triple) K::run(a, wv0, dcl0); else Cw<P, ND, H, PK, W16, false>::run(a, wv0, dcl0);
   } else {
-    Cw<P, ND, H, PK, W16, false>::run(a);
+    Cw<P, ND, H, PK, W16, false>::run(a, wv0, dcl0);
+  }
+}
+
+// WB = workgroup-size bound (VGPR budget = 512 / (WB / 256) per lane).
+// TR: the kernel holds both forms of the row loop (Cw::TR3): the triple-column form for the workgroups whose tile does
+// not hold the image's last two columns, the plain form for the others.
+template <int P, int ND, int H, bool PK, int WB, bool W16, bool TR = false, bool MIX = false>
+__global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
+{
+  if constexpr (MIX) {
+    static_assert((W16 && !PK && ND == 8 && !TR) || (PK && P == 4 && !W16 && ND >= 8),
+                  "mixed chunks: unpacked on the u16 ring (8 + 4), or packed P = 4 (ND, ND - 4)");
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wv < a.nwa) run_group<P, ND, H, PK, W16, TR>(a, 0, 0);
+    else run_group<P, MixChunk<P, ND, PK>::NDB, H, PK, W16, TR>(a, a.nwa, a.nwa * ND);
+  } else {
+    run_group<P, ND, H, PK, W16, TR>(a, 0, 0);
   }
 }
 

@@ -8,10 +8,11 @@
 
 namespace sadhip {
 
-// nw waves per workgroup; the LAST nwh of them own nd/2 candidates each (mixed-chunk plans, 0 otherwise), the others nd
+// nw waves per workgroup; the LAST nwh of them own ndh() candidates each (mixed-chunk plans, 0 otherwise), the others nd
 struct Plan {
   int p, nd, nw; bool pk, extra, w16; int nwh = 0;
-  int slots() const { return (nw - nwh) * nd + nwh * (nd / 2); }     // candidates of the pass without the odd one
+  int ndh() const { return pk ? nd - 4 : nd / 2; }                   // chunk of the trailing waves (MixChunk in colwave_kernel.h)
+  int slots() const { return (nw - nwh) * nd + nwh * ndh(); }        // candidates of the pass without the odd one
 };
 
 // LDS bytes of one workgroup of a plan (the layout at the top of Cw::run): 2h+3 ring rows and the

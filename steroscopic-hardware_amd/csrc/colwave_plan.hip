@@ -89,7 +89,8 @@ static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int
       const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 &&
                        ((nd == 8 && (nw <= w16_nw8 || nwh) && ((pk && h == 7 && !nwh) || (!pk && h >= 8 && maxdisp <= 255))) ||
                         (nd == 4 && nw % 2 == 0 && env_int("SADHIP_TUNE_W16ND4", 1) != 0 && !pk && h >= 8 && maxdisp <= 255));
-      if (nwh && !(w16 && !pk && nd == 8)) return;
+      // mixed chunks: unpacked 8 + 4 on the u16 ring; packed P = 4 (nd, nd - 4), 4 + 4 waves
+      if (nwh && !((w16 && !pk && nd == 8) || (pk && p == 4 && nd >= 12 && nw == 8 && nwh == 4))) return;
       if (h > 8 && nd == 8 && nw > 8 && !w16) return;           // ... and so does ND 8 with two-lane halos on the u32 ring (256-VGPR builds: <= 8 waves)
       // LDS: (2h+4) ring rows of L[TW] + R[TW + slots + 4 (8)] pixels, two row buffers, the output LUT
       Plan cand{p, nd, nw, pk, false, w16};
@@ -106,7 +107,7 @@ static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int
       // the busiest SIMD: waves go to the SIMDs round-robin (wave i -> SIMD i mod 4, tools/ubench/simd_map.hip); the last
       // wave carries the odd candidate
       long simd[4] = {0, 0, 0, 0};
-      for (int i = 0; i < nw; ++i) simd[i % 4] += per_wave(i >= nw - nwh ? nd / 2 : nd, extra && i == nw - 1);
+      for (int i = 0; i < nw; ++i) simd[i % 4] += per_wave(i >= nw - nwh ? cand.ndh() : nd, extra && i == nw - 1);
       const long busiest = std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3]));
       // waves a CU can hold of this plan (LDS; 128 VGPRs = 16 waves for the unpacked kernels): with one
       // 4-wave workgroup per CU nothing hides its latencies (measured: BlockSize 16, D 16 as 4 waves x 4
@@ -125,6 +126,7 @@ static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int
     for (int nw = 4; nw <= 16; ++nw) consider(nd, nw, 0);       // (two-wave workgroups for D <= 48 measured 25-35 % slower)
     if (nd == 8 && p == 8 && !pk && env_int("SADHIP_TUNE_MIX", 1) != 0)
       for (int nwa = 4; nwa <= 12; nwa += 4) consider(8, nwa + 4, 4);
+    if (p == 4 && pk && nd >= 12 && env_int("SADHIP_TUNE_MIX", 1) != 0) consider(nd, 8, 4);   // 4 waves of nd + 4 of nd - 4
   }
   return best;
 }

@@ -53,7 +53,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   a.j = j;
   a.nw = pl.nw;
   a.nwa = pl.nw - pl.nwh;
-  a.slots = a.nwa * ND + pl.nwh * (ND / 2);
+  a.slots = a.nwa * ND + pl.nwh * MixChunk<P, ND, PK>::NDB;
   a.xw = pl.extra ? pl.nw - 1 : -1;
   a.ksh = PK ? 16 : 32 - __builtin_clz((unsigned)j.maxdisp);  // unpacked: 2^ksh > maxdisp
   a.pixshift = PK ? 0 : a.ksh;
@@ -223,7 +223,7 @@ int describe_fast(const Job& j, char* buf, int cap, bool geometry)
 static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hipStream_t s, bool dry, PassGeom* geom)
 {
   const int h = j.block / 2;
-  if ((pl.w16 && pl.p != 8) || (pl.nwh && !pl.w16)) return hipErrorInvalidValue;
+  if ((pl.w16 && pl.p != 8) || (pl.nwh && !(pl.w16 || (pl.pk && pl.p == 4)))) return hipErrorInvalidValue;
   if (pl.w16 && pl.pk && pl.nd == 8 && h == 7) return launch_t<8, 8, 7, true, 1024, true>(j, pl, io, s, dry, 0, geom);
   // unpacked on the u16 ring, 128-VGPR builds (up to 16 waves per workgroup, two or three workgroups per CU): chunks of 8 and of 4
 #define SADHIP_W16U(HH) \
@@ -232,6 +232,17 @@ static hipError_t launch_pass(const Job& j, const Plan& pl, const PassIo& io, hi
   if (pl.w16 && !pl.pk && pl.nd == 4 && h == HH) return launch_t<8, 4, HH, false, 1024, true>(j, pl, io, s, dry, 0, geom)
   SADHIP_W16U(8); SADHIP_W16U(9); SADHIP_W16U(10); SADHIP_W16U(11); SADHIP_W16U(12); SADHIP_W16U(13); SADHIP_W16U(14); SADHIP_W16U(15);
   if (pl.w16) return hipErrorInvalidValue;
+  // packed P = 4 with mixed chunks (4 waves of ND + 4 of ND - 4): BlockSize 9 / 15 in their two-form kernels
+  if (pl.nwh && pl.pk && pl.p == 4) {
+#define SADHIP_PMIX(NDD, HH, TRR) if (pl.nd == NDD && h == HH) return launch_t<4, NDD, HH, true, 1024, false, TRR, true>(j, pl, io, s, dry, 0, geom)
+#define SADHIP_PMIX_LOW(NDD) SADHIP_PMIX(NDD, 1, false); SADHIP_PMIX(NDD, 2, false); SADHIP_PMIX(NDD, 3, false); SADHIP_PMIX(NDD, 4, kTripleColumns)
+    SADHIP_PMIX_LOW(12); SADHIP_PMIX_LOW(16); SADHIP_PMIX_LOW(20); SADHIP_PMIX_LOW(24);
+    SADHIP_PMIX(12, 5, false); SADHIP_PMIX(16, 5, false); SADHIP_PMIX(12, 6, false); SADHIP_PMIX(16, 6, false);
+    SADHIP_PMIX(12, 7, kTripleColumns); SADHIP_PMIX(16, 7, kTripleColumns);
+#undef SADHIP_PMIX_LOW
+#undef SADHIP_PMIX
+    return hipErrorInvalidValue;
+  }
 #define SADHIP_CASE(PP, NDD, HH, PKK) \
   if (pl.p == PP && pl.nd == NDD && h == HH && pl.pk == PKK) return launch_t<PP, NDD, HH, PKK>(j, pl, io, s, dry, 0, geom)
   // BlockSize 9: triple-column form for the tiles left of the image's last two columns, plain form for the rest

@@ -509,6 +509,52 @@ def test_u16_ring_chunks_of_four_and_mixed_chunk_plans(ctx):
         assert torch.equal(a, b), (block, D)
 
 
+def test_packed_mixed_chunk_plans(ctx):
+    """Round 4, the packed kernels (BlockSize <= 15): 4 waves of ND candidates followed by 4 waves of ND - 4 (+ the odd one) --
+    81 = 4*12 + 4*8 + 1 (BlockSize 11..15), 113 = 4*16 + 4*12 + 1, 145 = 4*20 + 4*16 + 1, 177 = 4*24 + 4*20 + 1 (BlockSize <= 9), and the
+    last pass of 208 / 240.  BlockSize 9 and 15 hold four row loops there (two chunk sizes x triple-column / plain form): widths
+    around their tile boundaries (one tile + 2, two tiles + 2, ...), so that both forms run in one launch.  Random, shifted,
+    extreme and flat frames; every frame against the generic path on the device, two rows of each against the oracle."""
+    import torch
+    rng = np.random.default_rng(45)
+    cases = {3: (112, 144, 176, 240), 5: (112, 176), 7: (112, 144, 240), 9: (112, 144, 176, 240), 11: (80, 112, 208, 240),
+             13: (80, 112, 208), 15: (80, 112, 208, 240)}
+    for block, Ds in cases.items():
+        hh = block // 2
+        hgt = 2 * hh + 9
+        for D in Ds:
+            pl = capi.plan_describe(1920, hgt, block, D)
+            assert pl and pl[-1]["packed"] == 1 and pl[-1]["nwh"] == 4 and pl[-1]["nw"] == 8 and pl[-1]["extra"] == 1, (block, D, pl)
+            for w in ((258, 507, 745) if block == 9 else (258, 498, 741) if block == 15 else (301, 770)):
+                if w <= D + 2 * hh + 2:
+                    continue                                    # narrow frames run the unpacked variant
+                L = rng.integers(0, 256, size=(4, hgt, w), dtype=np.uint8)
+                R = rng.integers(0, 256, size=(4, hgt, w), dtype=np.uint8)
+                R[1] = np.roll(L[1], -min(D, 37), axis=1)
+                L[2] = 255; R[2] = 0; R[2][:, w // 3:] = 255; R[2][:, 2 * w // 3:] = 0
+                L[3] = 91; R[3] = 91
+                Ls, Rs = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+                a, b = torch.full_like(Ls, 0xCD), torch.full_like(Ls, 0xEE)
+                ctx.disparity_dev(Ls, Rs, a, block, D, capi.FLAG_RAW)
+                assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+                ctx.disparity_dev(Ls, Rs, b, block, D, capi.FLAG_RAW | capi.FLAG_FORCE_GENERIC)
+                torch.cuda.synchronize()
+                got = a.cpu().numpy()
+                assert np.array_equal(got, b.cpu().numpy()), (block, w, D)
+                for i in range(4):
+                    reg = (0, hh + 3, w, hh + 5)
+                    assert np.array_equal(got[i][hh + 3:hh + 5], oracle.disparity_closed(L[i], R[i], block, D, region=reg, raw=True)), (block, w, D, i)
+    for block, D in ((9, 112), (15, 80), (7, 176)):               # 1080p width, the batched strip geometry
+        g = torch.Generator(device="cuda").manual_seed(block * 1000 + D)
+        Ls = torch.randint(0, 256, (6, 60, 1920), dtype=torch.uint8, device="cuda", generator=g)
+        Rs = torch.roll(Ls, -23, dims=2) ^ (torch.randint(0, 16, Ls.shape, device="cuda", generator=g) == 0).to(torch.uint8)
+        a, b = torch.empty_like(Ls), torch.empty_like(Ls)
+        ctx.disparity_dev(Ls, Rs, a, block, D)
+        ctx.disparity_dev(Ls, Rs, b, block, D, capi.FLAG_FORCE_GENERIC)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (block, D)
+
+
 def test_multi_pass_disparity_ranges(ctx):
     """D+1 candidates beyond the 16 waves of a workgroup run as several launches that hand a u32 key
     per pixel from pass to pass (colwave_plan.hip, plan_job): every UI value of MaxDisparity

@@ -25,7 +25,7 @@ def run(ncases=300, seed=0):
             w = int(rng.choice([w, rng.integers(240, 800), rng.integers(800, 4000)]))
         r4 = rng.random() < 0.2                                     # round 4: u16 ring with chunks of 4, mixed-chunk workgroups (BlockSize >= 16, D = 16 mod 32)
         if r4:
-            block = int(rng.integers(16, 32))
+            block = int(rng.integers(16, 32)) if rng.random() < 0.5 else int(rng.choice([3, 5, 7, 9, 9, 11, 13, 15, 15]))   # ... and the packed (ND, ND - 4) plans
             w = int(rng.choice([rng.integers(300, 700), rng.integers(700, 2100)]))
         D = int(rng.choice([rng.integers(1, 20), rng.choice([16, 32, 48, 64, 96, 128, 160, 192, 256]), rng.integers(20, 400)]))
         if r4:
