@@ -358,7 +358,10 @@ struct Cw {                                         // P columns per lane: 4 (pa
 
   // ---- vertical slide: C += |L-R|(entering row) ; C -= |L-R|(leaving row) -----------------------
   // lin/lout: this lane's P L values; rin/rout: its NRV R values, value m = column x0 - (dc+ND-1) + m.
-  static __device__ __forceinline__ void update_columns(unsigned (&C)[P][NC], Src lin, Src rin, Src lout, Src rout)
+  // leave = false (the first 2h+1 steps of a strip: the window is not full yet, the "leaving row" is the row of zeros):
+  // only the entering row is accumulated -- 40 % of a warm-up step, which short strips (single frames: 12 rows + 8 warm-up
+  // rows per strip) repeat for every strip.
+  static __device__ __forceinline__ void update_columns(unsigned (&C)[P][NC], Src lin, Src rin, Src lout, Src rout, const bool leave)
   {
     {
       unsigned li[P], ri[NRV];
@@ -379,7 +382,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
       }
     }
     __builtin_amdgcn_sched_barrier(0);                    // keep the two operand sets from overlapping
-    {
+    if (leave) {
       unsigned lo[P], ro[NRV];
       load_px(lout, lo);
       load_px<NRV, R_A16>(rout, ro);
@@ -412,7 +415,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
   // column sums here: lin/rxin point at this lane's L pixels and at the 16-byte aligned block whose
   // element XOFF is R column x0 - dx.  Pixels are plain bytes (packed) or pre-shifted (unpacked):
   // v_sad_u32 accumulates the right thing in both.
-  static __device__ __forceinline__ void extra_update(unsigned (&CX)[P][1], Src lin, Src rxin, Src lout, Src rxout)
+  static __device__ __forceinline__ void extra_update(unsigned (&CX)[P][1], Src lin, Src rxin, Src lout, Src rxout, const bool leave)
   {
     constexpr int NX = XOFF == 7 ? 16 : P + 4;            // elements XOFF .. XOFF+P-1 are used
     {
@@ -426,7 +429,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    {
+    if (leave) {
       unsigned lo[P], ro[NX];
       load_px(lout, lo);
       load_px(rxout, ro);
@@ -1034,8 +1037,9 @@ struct Cw {                                         // P columns per lane: 4 (pa
 #pragma unroll
       for (int p = 0; p < P; ++p) best[p] = KEY_INVALID;
       const bool out_row = t >= 2 * H;
+      const bool leave = t > 2 * H;                       // a row leaves the window (before: slot_out is the row of zeros)
       if (lane_valid) update_columns(C, Src{rin + lofs, rin + lofs + lhalf}, Src{rin + rofs, rin + rofs + rhalf},
-                                     Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rofs, rout + rofs + rhalf});
+                                     Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rofs, rout + rofs + rhalf}, leave);
       SADHIP_STAMP(0);
       if (out_row) {
         if (NEED_MASK && key_mask) {                 // leftmost tiles only
@@ -1050,7 +1054,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
         __builtin_amdgcn_sched_barrier(0);
         if (lane_valid)
           extra_update(CX, Src{rin + lofs, rin + lofs + lhalf}, Src{rin + rxofs, rin + rxofs + rhalf},
-                       Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rxofs, rout + rxofs + rhalf});
+                       Src{rout + lofs, rout + lofs + lhalf}, Src{rout + rxofs, rout + rxofs + rhalf}, leave);
         if (out_row) {
           if constexpr (NEED_MASK) reduce_row<2, ND>(CX, M, best, (unsigned)dx, 1);   // also drops the empty high half
           else reduce_row<0, 0>(CX, M, best, (unsigned)dx, 1);

@@ -24,7 +24,7 @@ int env_int(const char* name, int dflt)
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
                                         "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE",
-                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX", "SADHIP_TUNE_TAILPCT"};
+                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX", "SADHIP_TUNE_TAILPCT", "SADHIP_TUNE_WARMPCT"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -201,6 +201,7 @@ long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_ro
   const double slots = (double)cus * per_cu;
   double best = 1e300;
   long best_ns = 1;
+  const int warm_pct = env_int("SADHIP_TUNE_WARMPCT", 100);
   for (long ns = 1; ns <= max_strips; ++ns) {
     const long th = (rows + ns - 1) / ns;
     if ((rows + th - 1) / th != ns) continue;                   // this strip height gives fewer strips: counted there
@@ -211,7 +212,9 @@ long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_ro
     // workgroup's duration -- workgroups are handed out as slots free up, the busiest-CU round count overstates the wait
     const int tail_pct = env_int("SADHIP_TUNE_TAILPCT", 0);
     if (tail_pct > 0 && k > per_cu) t = (double)w / slots + tail_pct / 100.0;
-    const double cost = t * (double)(th + h2 + 4);
+    // a warm-up row costs less than an output row: no window sums, no argmin and (round 4) no leaving-row half of the
+    // vertical update -- `warm_pct` % of a row (tuning aid SADHIP_TUNE_WARMPCT)
+    const double cost = t * ((double)th + (double)h2 * warm_pct / 100.0 + 4.0);
     if (cost < best * 0.999) { best = cost; best_ns = ns; }     // ties: fewer strips
   }
   return best_ns;

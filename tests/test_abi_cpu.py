@@ -80,7 +80,7 @@ def test_no_column_wave_kernel_spills():
     select spilled 14-21 VGPRs, 60-88 bytes of scratch per lane).  SGPR -> VGPR-lane parking (no memory
     traffic) is tolerated only in the lane-mask families (packed h = 6, 7: up to 7 64-bit masks live across
     the row loop on top of a kernel that already uses ~100 SGPRs), bounded at 12 (round 2 started at 13-25);
-    and in the BlockSize-9 kernels, which hold two forms of the row loop behind a per-workgroup branch (5-13);
+    and in the BlockSize-9 / 15 kernels, which hold two forms of the row loop behind a per-workgroup branch (1-20);
     everything else reports 0 there too.  DESIGN.md section 6b has the measured alternatives."""
     import subprocess
     csrc = os.path.join(REPO, "steroscopic-hardware_amd", "csrc")
@@ -105,7 +105,7 @@ def test_no_column_wave_kernel_spills():
         # two forms): up to 46 SGPRs parked in VGPR lanes (no memory traffic; measured 5-30 % faster than the uniform plans
         # they replace, profiles/r04_sweep_packed_mixed.txt)
         mixed_family = m.group(6) == "1"
-        bound = (48 if m.group(4) == "1" else 4) if mixed_family else 18 if two_form_family else 12
+        bound = (48 if m.group(4) == "1" else 4) if mixed_family else 20 if two_form_family else 12
         if sc or vs or (ss and not (lane_mask_family or two_form_family or mixed_family)) or ss > bound:
             bad.append((name, sc, ss, vs))
     assert not bad, bad

@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(1024) k_block(unsigned* io, int iters)
     const int so = (MODE & 128) ? slot * 584 : 0;                    // ring rows of 584 dwords
     const int so2 = (MODE & 128) ? ((slot + 2) % 11) * 584 : 256;
     using S = typename K::Src;
-    if (MODE & 1) K::update_columns(C, S{l + so, l + so}, S{r + so, r + so}, S{l + so2, l + so2}, S{r + so2, r + so2});
+    if (MODE & 1) K::update_columns(C, S{l + so, l + so}, S{r + so, r + so}, S{l + so2, l + so2}, S{r + so2, r + so2}, true);
     slot = slot + 1 == 11 ? 0 : slot + 1;
     if (MODE & 32) { for (int p = 0; p < P; ++p) for (int q = 0; q < NC; ++q) C[p][q] += (unsigned)it & 1u; }   // defeat hoisting
     if (MODE & 2) K::template reduce_row<0, 0>(C, M, best, 0u, ND);
