@@ -61,7 +61,10 @@ struct CwArgs {
                    // (MixChunk: ND/2 unpacked, ND-4 packed).  nwa == nw otherwise
   int slots;       // candidates of the pass without the odd one: nwa*ND + (nw - nwa)*NDB
   int xw;          // wave that also owns candidate `slots` (the 16k+1-th), or -1
-  int ksh;         // bits of the disparity field of a key (unpacked: 2^ksh > maxdisp; packed: 16)
+  int ksh;         // bits of the disparity field of a key INSIDE a pass (packed: 16, the field holds d itself; unpacked:
+                   // 2^ksh > the pass's slot count, the field holds d - dbase -- at most 8 bits, so the pre-shifted pixels fit
+                   // the u16 ring whatever MaxDisparity is)
+  int kshg;        // ... of a key that travels between passes / is turned into the output (unpacked: 2^kshg > maxdisp; packed: 16)
   int pixshift;    // left shift applied to pixels landing in LDS (unpacked: ksh; packed: 0)
   int dpad;        // columns of R kept left of the tile (== 3 mod 4, >= largest candidate)
   int tx0;         // origin of tile 0 (<= 0, == w mod P)
@@ -885,7 +888,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
       for (int v = 0; v < MAXR; ++v)
         if (mine_r(v)) dst[TW + ir0 + 64 * v] = (Px)(PK ? pfr[v] : pfr[v] << a.pixshift);
     };
-    const unsigned kmask = (1u << a.ksh) - 1u;
+    const unsigned kmask = PK ? 0xffffu : (1u << a.ksh) - 1u, gmask = PK ? 0xffffu : (1u << a.kshg) - 1u;   // (packed: 16-bit field, a constant)
     auto finalize = [&](int t) {                          // output row of step t, this wave's pixels
       const int y = ys + t - 2 * H;
       unsigned* rb = rowbest + (t & 1) * RBW;
@@ -899,12 +902,17 @@ struct Cw {                                         // P columns per lane: 4 (pa
           unsigned k = rb[ri];
           rb[ri] = KEY_INVALID;
           if (x >= ox0 && x < ox1) {
+            if constexpr (!PK) {
+              // unpacked: the pass's key (SAD << ksh) | (d - dbase) becomes the travelling key (SAD << kshg) | d; a key
+              // with a penalty in it (a candidate that does not exist for this pixel: >= 2^27) becomes "no candidate"
+              k = k >= (1u << 27) ? KEY_INVALID : (((k >> a.ksh) << a.kshg) | ((k & kmask) + (unsigned)a.dbase));
+            }
             if (a.kin) k = min(k, a.kin[krow + (unsigned)(x - j.x0)]);
             if (a.kout) {
               a.kout[krow + (unsigned)(x - j.x0)] = k;
             } else {
               // x <= h: d = 0 is the only candidate (sad.go:66-69)
-              const unsigned dk = k & kmask;
+              const unsigned dk = k & gmask;
               const unsigned d = x <= H ? 0u : min(dk, (unsigned)j.maxdisp);
               orow[(unsigned)(x - j.ox)] = lut[d];
             }
@@ -971,7 +979,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
         return (col < d && (d - 1 - col) % B1 < CW) ? PEN : 0u;
       } else {
         const bool biased = ((unsigned)(col + B1 * 4096) % (unsigned)B1) == 0u;
-        return (biased ? (unsigned)d : 0u) + ((in && (col < d || d > j.maxdisp)) ? PEN : 0u);
+        return (biased ? (unsigned)(d - a.dbase) : 0u) + ((in && (col < d || d > j.maxdisp)) ? PEN : 0u);   // the key's field is d - dbase
       }
     };
     unsigned C[P][NC], CX[P][1];

@@ -81,14 +81,14 @@ static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int
       if (p == 4 && h > 4 && nd > 16) return;                   // two-lane halo kernels exist for ND 4, 8, 12, 16
       // u16 ring pixels where the u32 ring leaves room for one workgroup per CU only (instantiated for packed h = 7,
       // chunk size 8, and for unpacked h >= 8, chunk sizes 8 and 4 -- the latter with an even wave count: its ring
-      // rows are whole 16-byte blocks only then; unpacked pixels << bitlen(D) must fit 16 bits).
+      // rows are whole 16-byte blocks only then; unpacked pixels are shifted by bitlen(slots) <= 8 bits: they always fit).
       // Chunks of 8 on the u16 ring: up to 8 waves for h = 8 (beyond, the u32 ring's 16-wave workgroups measured 1-3 %
       // faster: B16 D96 54.7 vs 56.6 us), up to 16 for the two-lane halo kernels, h > 8 (one pass of 11-16 waves instead of
       // two passes of 8: B21 D96 65.5 -> 59.5 us, D128 76.6 -> 72.8)
       const int w16_nw8 = env_int("SADHIP_TUNE_W16NW", h > 8 ? 16 : 8);
       const bool w16 = env_int("SADHIP_TUNE_W16", 1) != 0 && p == 8 &&
-                       ((nd == 8 && (nw <= w16_nw8 || nwh) && ((pk && h == 7 && !nwh) || (!pk && h >= 8 && maxdisp <= 255))) ||
-                        (nd == 4 && nw % 2 == 0 && env_int("SADHIP_TUNE_W16ND4", 1) != 0 && !pk && h >= 8 && maxdisp <= 255));
+                       ((nd == 8 && (nw <= w16_nw8 || nwh) && ((pk && h == 7 && !nwh) || (!pk && h >= 8))) ||
+                        (nd == 4 && nw % 2 == 0 && env_int("SADHIP_TUNE_W16ND4", 1) != 0 && !pk && h >= 8));
       // mixed chunks: unpacked 8 + 4 on the u16 ring; packed P = 4 (nd, nd - 4), 4 + 4 waves
       if (nwh && !((w16 && !pk && nd == 8) || (pk && p == 4 && nd >= 12 && nw == 8 && nwh == 4))) return;
       if (h > 8 && nd == 8 && nw > 8 && !w16) return;           // ... and so does ND 8 with two-lane halos on the u32 ring (256-VGPR builds: <= 8 waves)
@@ -158,13 +158,13 @@ static std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
   for (int variant = (h <= 7 && !narrow && env_int("SADHIP_TUNE_PK", 1) != 0) ? 0 : 1; variant < 2; ++variant) {
     const bool pk = variant == 0;
     if (!pk && h < 3) break;                                    // unpacked variants exist for h >= 3 only
-    // unpacked keys ((2h+1)^2*255 << bitlen(D)) must stay below the 2^27 penalty
-    const int b1 = 2 * h + 1, ksh = 32 - __builtin_clz((unsigned)maxdisp);
-    if (!pk && ((long long)b1 * b1 * 255 << ksh) >= (1LL << 27)) break;
+    // (unpacked keys inside a pass are (SAD << bitlen(slots)) | (d - dbase) with at most 129 candidates per pass:
+    //  31^2 * 255 << 8 stays below the 2^27 penalty for every block size, whatever MaxDisparity is -- round 4; before,
+    //  the field held d itself and BlockSize 31 with D >= 512 went to the generic kernel)
     const bool exact = pk && h > 5;
     // full passes: 8 waves of ND 16 (P 4) / 16 waves of ND 8 (P 8); two-lane halos: 8 waves of ND 8
     // (round 4: the two-lane halo kernels too -- 16 waves of 8 on the u16 ring where D <= 255, else 8 waves of 8)
-    const int chunk = env_int("SADHIP_TUNE_CHUNK", (h <= 8 || (!pk && maxdisp <= 255)) ? 128 : 64);
+    const int chunk = env_int("SADHIP_TUNE_CHUNK", (h <= 8 || !pk) ? 128 : 64);
     passes.clear();
     int base = 0, rem = maxdisp + 1;
     while (rem > 0) {

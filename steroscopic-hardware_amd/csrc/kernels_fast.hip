@@ -55,9 +55,12 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   a.nwa = pl.nw - pl.nwh;
   a.slots = a.nwa * ND + pl.nwh * MixChunk<P, ND, PK>::NDB;
   a.xw = pl.extra ? pl.nw - 1 : -1;
-  a.ksh = PK ? 16 : 32 - __builtin_clz((unsigned)j.maxdisp);  // unpacked: 2^ksh > maxdisp
-  a.pixshift = PK ? 0 : a.ksh;
+  a.kshg = PK ? 16 : 32 - __builtin_clz((unsigned)j.maxdisp);     // travelling keys: 2^kshg > maxdisp
+  a.pixshift = 0;                                               // (unpacked: set below, once the slot count is known)
   a.dbase = io.dbase; a.kin = io.kin; a.kout = io.kout; a.kw = io.kw;
+  a.ksh = PK ? 16 : 32 - __builtin_clz((unsigned)a.slots);        // unpacked: the field holds d - dbase <= slots (the odd candidate)
+  if (!PK) a.pixshift = a.ksh;
+  if (!PK && (a.ksh > 8 || ((long long)(2 * H + 1) * (2 * H + 1) * 255 << a.ksh) >= (1LL << 27))) return hipErrorInvalidValue;   // keys below the 2^27 penalty, pixels within 16 bits
   a.dpad = a.slots + K::XOFF;                                 // keeps every lane's R operands 16-byte aligned (u16 ring, chunks of 4: 8-byte)
   const int RW = K::TW + a.dpad + 1;
   // Row streaming and output are shared by the waves.  The wave that carries the odd candidate does

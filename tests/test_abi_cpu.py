@@ -80,7 +80,7 @@ def test_no_column_wave_kernel_spills():
     select spilled 14-21 VGPRs, 60-88 bytes of scratch per lane).  SGPR -> VGPR-lane parking (no memory
     traffic) is tolerated only in the lane-mask families (packed h = 6, 7: up to 7 64-bit masks live across
     the row loop on top of a kernel that already uses ~100 SGPRs), bounded at 12 (round 2 started at 13-25);
-    and in the BlockSize-9 / 15 kernels, which hold two forms of the row loop behind a per-workgroup branch (1-20);
+    and in the BlockSize-9 / 15 kernels, which hold two forms of the row loop behind a per-workgroup branch (1-14);
     everything else reports 0 there too.  DESIGN.md section 6b has the measured alternatives."""
     import subprocess
     csrc = os.path.join(REPO, "steroscopic-hardware_amd", "csrc")
@@ -101,11 +101,11 @@ def test_no_column_wave_kernel_spills():
         # the BlockSize-9 kernels hold two forms behind a per-workgroup branch (triple-column / plain, Cw::TR3)
         two_form_family = m.group(5) == "1"
         # round 4: the mixed-chunk kernels hold two chunk sizes of the row loop behind a per-wave branch -- unpacked 8 + 4 on the
-        # u16 ring (<= 3 parked SGPRs); packed P = 4 (ND, ND - 4), where BlockSize 9 / 15 hold FOUR row loops (two chunk sizes x
+        # u16 ring (<= 6 parked SGPRs); packed P = 4 (ND, ND - 4), where BlockSize 9 / 15 hold FOUR row loops (two chunk sizes x
         # two forms): up to 46 SGPRs parked in VGPR lanes (no memory traffic; measured 5-30 % faster than the uniform plans
         # they replace, profiles/r04_sweep_packed_mixed.txt)
         mixed_family = m.group(6) == "1"
-        bound = (48 if m.group(4) == "1" else 4) if mixed_family else 20 if two_form_family else 12
+        bound = (48 if m.group(4) == "1" else 8) if mixed_family else 16 if two_form_family else 12
         if sc or vs or (ss and not (lane_mask_family or two_form_family or mixed_family)) or ss > bound:
             bad.append((name, sc, ss, vs))
     assert not bad, bad
@@ -263,9 +263,10 @@ def test_planner_invariants_over_the_parameter_space():
                         assert slots + ps["extra"] == ps["count"]           # lane-mask variants: exact plans only
                 else:
                     assert hh >= 3 and ps["p"] == 8
-                    assert ((2 * hh + 1) ** 2 * 255 << maxdisp.bit_length()) < (1 << 27)
+                    # keys inside a pass: (SAD << bitlen(slots)) | (d - dbase), below the 2^27 penalty; pixels << bitlen(slots) fit 16 bits
+                    assert slots.bit_length() <= 8 and ((2 * hh + 1) ** 2 * 255 << slots.bit_length()) < (1 << 27)
                 if ps["w16"]:
-                    assert ps["p"] == 8 and ps["nd"] in (4, 8) and (ps["packed"] or maxdisp <= 255)
+                    assert ps["p"] == 8 and ps["nd"] in (4, 8)
                     if ps["nd"] == 4:
                         assert not ps["packed"] and ps["nw"] % 2 == 0      # ring rows stay whole 16-byte blocks
                     elif hh <= 8 and not ps["nwh"]:

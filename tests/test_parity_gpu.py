@@ -509,6 +509,40 @@ def test_u16_ring_chunks_of_four_and_mixed_chunk_plans(ctx):
         assert torch.equal(a, b), (block, D)
 
 
+def test_unpacked_kernels_any_max_disparity(ctx):
+    """Round 4: inside a pass the unpacked kernels' keys hold d - dbase (at most 8 bits), the key that travels between passes
+    holds d: the u16 ring and the 2^27 penalty no longer limit MaxDisparity.  BlockSize 16 .. 31 with D = 256 (two passes of 16
+    waves on the u16 ring where round 3 ran four of 64 candidates), 300, 511, 512, 1000 and 4096 (round 3: BlockSize 31 from D 512
+    on was the generic kernel's) -- random, shifted and extreme frames against the oracle, and the generic path on the device."""
+    import torch
+    rng = np.random.default_rng(46)
+    for block, w, D in ((16, 700, 256), (17, 600, 300), (21, 900, 511), (31, 800, 512), (27, 1300, 1000), (31, 300, 256), (19, 4400, 4096), (16, 517, 257)):
+        hh = block // 2
+        hgt = 2 * hh + 5
+        pl = capi.plan_describe(w, hgt, block, D)
+        assert capi.kernel_kind(w, hgt, block, D) == capi.KIND_COLWAVE and len(pl) >= 2 and not pl[0]["packed"], (block, D, pl)
+        if block >= 18:
+            assert all(p["w16"] for p in pl), (block, D, pl)
+        L = rng.integers(0, 256, size=(3, hgt, w), dtype=np.uint8)
+        R = rng.integers(0, 256, size=(3, hgt, w), dtype=np.uint8)
+        R[1] = np.roll(L[1], -min(D - 3, w // 2), axis=1)               # a true shift deep in the range (the later passes win)
+        L[2] = 255; R[2] = 0; R[2][:, w // 3:] = 255
+        big = capi.Context(0, w, hgt, 1) if w > 3840 else ctx
+        Ls, Rs = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+        a, b = torch.full_like(Ls, 0xCD), torch.full_like(Ls, 0xEE)
+        big.disparity_dev(Ls, Rs, a, block, D)
+        assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+        big.disparity_dev(Ls, Rs, b, block, D, capi.FLAG_FORCE_GENERIC)
+        torch.cuda.synchronize()
+        got = a.cpu().numpy()
+        assert np.array_equal(got, b.cpu().numpy()), (block, w, D)
+        for i in range(3):
+            reg = (0, hh + 1, w, hh + 3)
+            assert np.array_equal(got[i][hh + 1:hh + 3], oracle.disparity_rows_mt(L[i], R[i], block, D, hh + 1, hh + 3, min(16, os.cpu_count() or 1))), (block, w, D, i)
+        if big is not ctx:
+            big.close()
+
+
 def test_packed_mixed_chunk_plans(ctx):
     """Round 4, the packed kernels (BlockSize <= 15): 4 waves of ND candidates followed by 4 waves of ND - 4 (+ the odd one) --
     81 = 4*12 + 4*8 + 1 (BlockSize 11..15), 113 = 4*16 + 4*12 + 1, 145 = 4*20 + 4*16 + 1, 177 = 4*24 + 4*20 + 1 (BlockSize <= 9), and the
