@@ -111,6 +111,11 @@ def _live_counters(frames, timeout_s=240):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return {"error": "rocprofv3 not found"}
+    # this process is itself running under a profiler (its tool library is preloaded / named in the environment): a nested
+    # rocprofv3 would inherit that -- leave the counters to the outer run and report the committed profile
+    under = [k for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH") if os.environ.get(k)]
+    if under or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "bench.py is running under a profiler (%s): no nested counter passes" % (", ".join(under) or "LD_PRELOAD")}
     got, t_all = {}, time.perf_counter()
     for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU"]):
         td = tempfile.mkdtemp(prefix="sadhip_pmc_", dir="/tmp")
