@@ -272,16 +272,41 @@ def _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, r
         for g in [g for g in (1, 2, 4, 8) if g <= max(ndev, 1)]:
             devices = [local] if g == 1 else list(range(g))
             with capi.Pool(devices, W, H) as pool:
-                dt, ok = timed(lambda: pool.batch(lefts, rights, block, maxdisp, flags, outs=outs))
-                k_sum, wall = pool.last_timing()
-                placement = pool.describe()
+                # entry e's frames (e, e + G, ...) live in memory its own worker thread allocated and first-touched
+                # (sadhip_pool_host_alloc): every device reads and writes memory of its own NUMA node
+                per = [(nf - e + g - 1) // g for e in range(g)]
+                bufs = [pool.host_alloc(e, 3 * per[e] * frame) for e in range(g)]
+                try:
+                    views = [bufs[e].view((3, per[e], H, W)) for e in range(g)]
+                    for i in range(nf):
+                        views[i % g][0, i // g] = blk[0, i]; views[i % g][1, i // g] = blk[1, i]
+                    pl = [views[i % g][0, i // g] for i in range(nf)]; pr = [views[i % g][1, i // g] for i in range(nf)]
+                    po = [views[i % g][2, i // g] for i in range(nf)]
+
+                    def run_pool():
+                        pool.batch(pl, pr, block, maxdisp, flags, outs=po)
+                    run_pool()
+                    best = None
+                    for _ in range(3):
+                        for v in views:
+                            v[2] = 0
+                        t0 = time.perf_counter()
+                        run_pool()
+                        dtp = time.perf_counter() - t0
+                        best = dtp if best is None or dtp < best else best
+                    dt, ok = best, all(np.array_equal(po[i], ref[i]) for i in range(nf))
+                    k_sum, wall = pool.last_timing()
+                    placement = pool.describe()
+                finally:
+                    del views, pl, pr, po
+                    for b in bufs:
+                        b.close()
             legs["pool"].append({"value": nf / dt, "unit": "pairs/s", "frames": nf, "devices": devices, "pcie_gb_per_s": 3 * frame * nf / dt / 1e9,
-                                 "entry": "sadhip_pool_batch_u8", "memory": "page-locked (sadhip_host_alloc)", "kernel_ms_sum": k_sum,
-                                 "matches_device_resident": ok, "workers": placement})
+                                 "entry": "sadhip_pool_batch_u8", "memory": "page-locked, per entry from sadhip_pool_host_alloc (allocated and first-touched by the entry's worker thread)",
+                                 "kernel_ms_sum": k_sum, "matches_device_resident": ok, "workers": placement})
         legs["pool_note"] = ("one context + host thread per device, frame i -> device i mod G, each worker thread pinned to the CPUs of its "
-                             "device's NUMA node (workers[].cpus; best effort); the frames here are ONE page-locked block allocated by the "
-                             "calling thread, so on a two-socket host half the devices read across the socket link -- a deployment allocates "
-                             "each device's frames from its worker's node")
+                             "device's NUMA node (workers[].cpus; best effort), each entry's frames in page-locked memory that worker allocated "
+                             "and first-touched: no device reads or writes across the socket link")
     return legs
 
 

@@ -45,7 +45,7 @@ extern "C" {
 #define SADHIP_ABI_VERSION 4   /* 2: flag validation, MIRROR_VERILOG, sadhip_last_kernel_kind, sadhip_pool_*;
                                 * 3: sadhip_disparity_lr_u8 (left / right images of different sizes), sadhip_host_* (page-locked
                                 *    host memory), sadhip_plan_describe_batch;
-                                * 4: sadhip_pool_describe / sadhip_device_describe (NUMA placement), sadhip_host_register
+                                * 4: sadhip_pool_describe / sadhip_device_describe / sadhip_pool_host_alloc (NUMA placement), sadhip_host_register
                                 *    refuses overlapping ranges, the generic kernel's work bound (SADHIP_GENERIC_MAX_WORK),
                                 *    "nwh" in the plan lines */
 
@@ -296,6 +296,10 @@ SADHIP_API int sadhip_pool_last_timing(sadhip_pool* pool, float* kernel_ms_sum, 
  * first-touch device i's frames -- i, i + G, ... -- from a thread running on entry i's cpus; frames in one block
  * allocated by one thread cross the socket link for half the devices of a two-socket host. */
 SADHIP_API int sadhip_pool_describe(const sadhip_pool* pool, char* buf, int cap);
+/* Page-locked memory for the frames of pool entry `entry` (frames entry, entry + G, ... of a batch), allocated AND first-touched
+ * by that entry's worker thread, i.e. on the CPUs next to its device: sadhip_host_alloc semantics otherwise (usable from every
+ * device; free with sadhip_host_free from any thread).  Not while a batch is running on the pool (it waits for it). */
+SADHIP_API int sadhip_pool_host_alloc(sadhip_pool* pool, int entry, size_t bytes, void** out);
 /* The same lookup for a host that drives ONE context itself (the Go shim's case): "device=<ordinal> pci=<bus id>
  * numa_node=<n or -1> cpus=<the device's local CPUs within this process's affinity mask, or ->".  A caller that pins the
  * thread making its calls to those CPUs (Go: runtime.LockOSThread + unix.SchedSetaffinity) and allocates its page-locked

@@ -77,6 +77,7 @@ SYMBOLS = {
     "sadhip_pool_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sadhip_pool_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "sadhip_device_describe": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "sadhip_pool_host_alloc": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
 }
 
 _LIB = None
@@ -208,6 +209,14 @@ class HostBuffer:
         _check(lib().sadhip_host_alloc(nbytes, C.byref(self._p)))
         self.nbytes = nbytes
         self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self._p.value))
+
+    @classmethod
+    def _adopt(cls, p, nbytes):
+        """Wraps page-locked memory the library has already allocated (sadhip_pool_host_alloc)."""
+        self = cls.__new__(cls)
+        self._p, self.nbytes = p, nbytes
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p.value))
+        return self
 
     def view(self, shape):
         return self.array[:int(np.prod(shape))].reshape(shape)
@@ -446,6 +455,13 @@ class Pool:
         n, w, h, ls, rs, outs, pa, pb, po = _frames(lefts, rights, outs)
         _check(lib().sadhip_pool_batch_u8(self._h, n, pa, pb, w, h, ls, rs, block, maxdisp, flags, po, w))
         return outs
+
+    def host_alloc(self, entry, nbytes):
+        """Page-locked memory allocated and first-touched by entry's worker thread (on the CPUs next to its device): a
+        HostBuffer (close() frees it)."""
+        p = C.c_void_p()
+        _check(lib().sadhip_pool_host_alloc(self._h, entry, nbytes, C.byref(p)))
+        return HostBuffer._adopt(p, nbytes)
 
     def describe(self):
         """Host placement of the pool's workers (sadhip_pool_describe): list of dicts entry, device, pci, numa_node,

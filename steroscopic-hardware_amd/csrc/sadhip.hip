@@ -1062,6 +1062,8 @@ struct PoolWorker {
   std::condition_variable cv;
   const PoolTask* task = nullptr;      // posted by the caller, cleared by the worker
   bool quit = false, done = false, started = false;
+  // sadhip_pool_host_alloc: page-locked memory allocated AND first-touched by this (pinned) thread
+  size_t alloc_bytes = 0; void* alloc_ptr = nullptr; bool alloc_pending = false, alloc_done = false; int alloc_status = SADHIP_OK;
   int status = SADHIP_OK;
   int frames = 0;
   float kernel_ms = 0.f;
@@ -1083,8 +1085,22 @@ void pool_worker_main(PoolWorker* me)
   me->cv.notify_all();
   for (;;) {
     std::unique_lock<std::mutex> lk(me->mu);
-    me->cv.wait(lk, [&] { return me->task != nullptr || me->quit; });
+    me->cv.wait(lk, [&] { return me->task != nullptr || me->quit || me->alloc_pending; });
     if (me->quit) return;
+    if (me->alloc_pending) {                                    // allocate + first-touch on this thread's node
+      const size_t bytes = me->alloc_bytes;
+      lk.unlock();
+      void* p = nullptr;
+      int ast = sadhip_host_alloc(bytes, &p);
+      if (ast == SADHIP_OK) memset(p, 0, bytes);
+      lk.lock();
+      me->alloc_ptr = p; me->alloc_status = ast;
+      if (ast != SADHIP_OK) snprintf(me->err, sizeof(me->err), "device entry %d: %s", me->index, g_err);
+      me->alloc_pending = false; me->alloc_done = true;
+      lk.unlock();
+      me->cv.notify_all();
+      continue;
+    }
     const PoolTask* t = me->task;
     lk.unlock();
     int st = SADHIP_OK;
@@ -1182,6 +1198,23 @@ extern "C" int sadhip_pool_size(const sadhip_pool* pool, int* n_devices)
 {
   if (!pool || !n_devices) return fail(SADHIP_ERR_NULL, "pool or n_devices is NULL");
   *n_devices = (int)pool->w.size();
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_pool_host_alloc(sadhip_pool* pool, int entry, size_t bytes, void** out)
+{
+  if (!pool || !out) return fail(SADHIP_ERR_NULL, "pool or out is NULL");
+  *out = nullptr;
+  if (entry < 0 || entry >= (int)pool->w.size()) return fail(SADHIP_ERR_ARG, "entry %d out of range [0,%d)", entry, (int)pool->w.size());
+  if (bytes == 0) return fail(SADHIP_ERR_ARG, "bytes=0");
+  std::lock_guard<std::mutex> call(pool->call_mu);            // not while a batch is running on the pool
+  PoolWorker& w = *pool->w[entry];
+  { std::lock_guard<std::mutex> lk(w.mu); w.alloc_bytes = bytes; w.alloc_ptr = nullptr; w.alloc_done = false; w.alloc_pending = true; }
+  w.cv.notify_all();
+  std::unique_lock<std::mutex> lk(w.mu);
+  w.cv.wait(lk, [&] { return w.alloc_done; });
+  if (w.alloc_status != SADHIP_OK) return fail(w.alloc_status, "%s", w.err);
+  *out = w.alloc_ptr;
   return SADHIP_OK;
 }
 

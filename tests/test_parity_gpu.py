@@ -966,6 +966,16 @@ def test_pool_workers_are_pinned_next_to_their_device():
         with pytest.raises(capi.SadHipError) as ei:
             capi.device_describe(99)
         assert ei.value.status == capi.ERR_NO_DEVICE
+        # per-entry page-locked memory, allocated and first-touched by the entry's worker thread
+        with pool.host_alloc(1, 3 * 320 * 100) as hb:
+            v = hb.view((3, 100, 320))
+            assert not v.any()                                    # first-touched (zeroed) by the worker
+            v[0], v[1] = sha.synth.synth_pair(78, 320, 100)
+            outs = pool.batch([v[0]], [v[1]], 9, 32, outs=[v[2]])
+            assert np.array_equal(outs[0], oracle.disparity_closed(v[0], v[1], 9, 32))
+        with pytest.raises(capi.SadHipError) as ei:
+            pool.host_alloc(2, 4096)
+        assert ei.value.status == capi.ERR_ARG
         # and the pool still computes: two contexts on the one device, frames round-robin
         L, R = sha.synth.synth_pair(77, 320, 100)
         outs = pool.batch([L] * 5, [R] * 5, 9, 32)
