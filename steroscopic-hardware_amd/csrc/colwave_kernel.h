@@ -568,9 +568,10 @@ struct Cw {                                         // P columns per lane: 4 (pa
       // no suffix sums at all (7 subtractions per candidate less) and one DPP add for the shared base -- 23 instructions
       // per candidate instead of 30.  Exact modulo 2^32 like every other sum here (penalised columns included).
       // The two subtractions are written as  n = left.prefix[p] - base ;  W = right.prefix[p+1] - n  in inline asm:
-      // on this toolchain v_subrev_u32_dpp D, S0, S1 computes dpp(S1) - S0 (tools/ubench/dpp_sub.hip), NOT S1 - dpp(S0)
-      // as hipcc assumes when it folds `base - dpp(x)` into it -- a silent miscompile (every key wrong); in both
-      // subtract forms the lane-shifted operand is the minuend, and v_sub_u32_dpp D = dpp(S0) - S1 is as documented.
+      // measured on this chip with this toolchain (tools/ubench/dpp_sub.hip, profiles/ubench_dpp_sub.txt),
+      // `v_subrev_u32_dpp D, a, b <shift>` gives shift(b) - a in 64 of 64 lanes, NOT b - shift(a) as hipcc assumes when it
+      // folds `base - dpp(x)` into it -- every key came out wrong; `v_sub_u32_dpp D, a, b` gives shift(a) - b, as the ISA
+      // text says.  Either way the lane-shifted operand is the minuend.
       // (s_nop 1: a DPP source needs two wait states after the VALU instruction that wrote it, and the compiler does
       // not look into asm.)
       unsigned base = r.ps[P] + from_left(r.ps[P]);

@@ -139,9 +139,10 @@ def test_abi3_entry_points_validate_and_fail_loudly_without_a_gpu():
 
 
 def test_no_kernel_contains_a_folded_dpp_reverse_subtract():
-    """On this toolchain `v_subrev_u32_dpp D, S0, S1` computes dpp(S1) - S0 on the hardware (tools/ubench/dpp_sub.hip,
-    run on the MI355X box), while hipcc folds `base - dpp(x)` into it as if it were S1 - dpp(S0): every key of the
-    BlockSize-16 kernel came out wrong in round 3.  The kernels write such subtractions as v_sub_u32_dpp in inline asm;
+    """Measured on the MI355X box (tools/ubench/dpp_sub.hip; output in profiles/ubench_dpp_sub.txt, encodings in
+    profiles/ubench_dpp_sub_disasm.txt): `v_subrev_u32_dpp D, a, b <lane shift>` gives shift(b) - a in 64 of 64 lanes, while
+    hipcc folds `b - dpp(a)` into that instruction as if it gave b - shift(a) (the compiled expression is right in 0 of 64 lanes):
+    every key of the BlockSize-16 kernel came out wrong in round 3.  The kernels write such subtractions as v_sub_u32_dpp in inline asm;
     this test fails if the compiler ever emits the reversed DPP form (any type) into a column-wave kernel again."""
     import subprocess
     import sys
