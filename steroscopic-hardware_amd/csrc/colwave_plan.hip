@@ -60,7 +60,12 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp)
     const Plan pl = plan_count_p(h, pk, count, exact, maxdisp, 4);
     if (pl.nw || force_p == 4 || h <= 4) return pl;
   }
-  return plan_count_p(h, pk, count, exact, maxdisp, 8);
+  Plan pl = plan_count_p(h, pk, count, exact, maxdisp, 8);
+  // packed h = 5 beyond what P = 4 covers (more than 129 candidates): a P = 8 plan only where it fits exactly on whole SIMD
+  // rounds (145 = 12 x 12 + 1); otherwise no plan here, and plan_job cuts the range into a full P = 4 pass + the rest
+  // (round 4: 161 / 177 candidates ran as 14 / 15 waves of 12 with idle slots)
+  if (pk && h == 5 && pl.nw && force_p != 8 && (pl.nw % 4 != 0 || pl.slots() + (pl.extra ? 1 : 0) != count)) pl.nw = 0;
+  return pl;
 }
 
 static Plan plan_count_p(int h, bool pk, int count, bool exact, int maxdisp, int p)

@@ -227,6 +227,20 @@ def test_whole_ui_parameter_grid_plans_on_the_fast_kernel():
     assert capi.kernel_kind(1920, 1080, 9, 64, capi.FLAG_FORCE_GENERIC) == 0
 
 
+def test_every_cell_of_the_ui_grid_has_an_exact_plan():
+    """Round 4: with the mixed-chunk plans every (BlockSize, MaxDisparity) the reference's UI can select -- and the defaults'
+    BlockSize 16 -- runs passes whose slots (+ the odd candidate) equal their candidates: nothing rounds up to a whole chunk,
+    no workgroup has a wave count that is not a multiple of 4 (a quarter of a SIMD round idle)."""
+    for block in list(range(3, 32, 2)) + [16]:
+        for maxdisp in range(16, 257, 16):
+            plan = capi.plan_describe(1920, 1080, block, maxdisp)
+            assert plan and sum(ps["count"] for ps in plan) == maxdisp + 1, (block, maxdisp)
+            for ps in plan:
+                ndh = ps["nd"] - 4 if ps["packed"] else ps["nd"] // 2
+                assert (ps["nw"] - ps["nwh"]) * ps["nd"] + ps["nwh"] * ndh + ps["extra"] == ps["count"], (block, maxdisp, ps)
+                assert ps["nw"] % 4 == 0 and ps["nwh"] % 4 == 0, (block, maxdisp, ps)
+
+
 def test_planner_invariants_over_the_parameter_space():
     """plan_job (colwave_plan.hip) through sadhip_plan_describe: passes tile [0, D] without gaps, stay
     inside the launch limits the kernel assumes, and keep the properties the kernel relies on."""
