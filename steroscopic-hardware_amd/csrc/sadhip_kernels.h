@@ -42,10 +42,8 @@ void note_launch(int kind);
 int last_launch_kind();
 
 // Stream-ordered scratch (the u32 / u64 key per pixel that travels between the passes of a multi-pass job, the running-sum
-// kernel's keys): allocated from the library's OWN memory pool of the current device, whose release threshold keeps up to
-// 1 GiB cached.  From the device's default pool (release threshold 0) every stream synchronise hands unused memory back to
-// the driver and the next call pays for a fresh 256 MB allocation: on some boxes that was 3 ms per call (MaxDisparity 192 with
-// BlockSize 16: 152 us per pair instead of 105, tools/ubench/malloc_async.hip).  The host application's pools are not touched.
+// kernel's keys): hipMallocAsync / hipFreeAsync on the job's stream, from the device's default memory pool (kernels_generic.hip
+// has the round-4 experiment with a pool of the library's own, and why it was withdrawn).
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s);
 hipError_t scratch_free(void* p, hipStream_t s);
 
