@@ -262,8 +262,9 @@ SADHIP_API int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, 
  * range only when no call that was given pointers into it is still running (every entry point has finished
  * with the caller's memory when it returns); a range that disappears under a running call is not an error --
  * the copies fall back to the pageable path -- but its memory must of course stay valid.
- * The known ranges are DISJOINT: sadhip_host_register of memory that overlaps a sadhip_host_alloc block or an earlier
- * registration (a sub-range, a super-range, a partial overlap) returns SADHIP_ERR_ARG and registers nothing. */
+ * The known ranges are DISJOINT page by page: sadhip_host_register of memory that shares a 4 KiB page with a sadhip_host_alloc
+ * block or an earlier registration (a sub-range, a super-range, a partial overlap, a neighbour that starts or ends inside the
+ * same page) returns SADHIP_ERR_ARG and registers nothing. */
 SADHIP_API int sadhip_host_alloc(size_t bytes, void** out);
 SADHIP_API int sadhip_host_free(void* p);
 SADHIP_API int sadhip_host_register(void* p, size_t bytes);

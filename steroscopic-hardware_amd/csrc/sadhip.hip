@@ -109,13 +109,19 @@ bool pin_insert(void* p, size_t bytes, bool owned)
   return true;
 }
 
-// [p, p + bytes) meets a known range
+// [p, p + bytes) meets a known range -- at PAGE granularity: page-locking works on whole pages, and two registrations that
+// share a page are two locks on it whose unlocks the driver has to keep apart (sadhip_host_register refuses that)
 bool pin_overlaps(const void* p, size_t bytes)
 {
-  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  constexpr uintptr_t PG = 4096;
+  const uintptr_t lo = (uintptr_t)p & ~(PG - 1), hi = ((uintptr_t)p + bytes + PG - 1) & ~(PG - 1);
   std::shared_lock<std::shared_mutex> lk(g_pin_mu);
-  auto it = std::upper_bound(g_pins.begin(), g_pins.end(), lo, [](uintptr_t v, const PinnedRange& q) { return v < q.lo; });
-  return (it != g_pins.end() && it->lo < hi) || (it != g_pins.begin() && std::prev(it)->hi > lo);
+  for (const PinnedRange& q : g_pins) {                       // (a handful of ranges; sorted by lo)
+    const uintptr_t qlo = q.lo & ~(PG - 1), qhi = (q.hi + PG - 1) & ~(PG - 1);
+    if (qlo < hi && lo < qhi) return true;
+    if (qlo >= hi) break;
+  }
+  return false;
 }
 
 // removes the range that STARTS at p; false when there is none of that kind
@@ -163,8 +169,9 @@ extern "C" int sadhip_host_register(void* p, size_t bytes)
 {
   if (!p) return fail(SADHIP_ERR_NULL, "p is NULL");
   if (bytes == 0) return fail(SADHIP_ERR_ARG, "bytes=0");
-  // ranges are disjoint: a sub-range of a sadhip_host_alloc block (already page-locked) or of an earlier registration is refused
-  if (pin_overlaps(p, bytes)) return fail(SADHIP_ERR_ARG, "[%p, +%zu) overlaps page-locked memory this library already knows", p, bytes);
+  // ranges are disjoint, page by page: a sub-range of a sadhip_host_alloc block (already page-locked), of an earlier
+  // registration, or a range that merely shares a 4 KiB page with one is refused
+  if (pin_overlaps(p, bytes)) return fail(SADHIP_ERR_ARG, "[%p, +%zu) shares a page with page-locked memory this library already knows", p, bytes);
   const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
   if (e != hipSuccess) {
     (void)hipGetLastError();

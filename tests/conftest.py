@@ -17,6 +17,42 @@ def pytest_configure(config):
     _ensure_built()
 
 
+def pytest_sessionstart(session):
+    """Which box is this?  One line on stderr (not captured: pytest.ini sets --capture=sys), so that a result -- or a native
+    abort -- of a GPU run can be tied to the host, driver and device it happened on (round 4 saw box-to-box differences:
+    DESIGN.md section 6 "box to box")."""
+    try:
+        import platform
+        import subprocess
+        import torch
+        if not torch.cuda.is_available():
+            return
+        info = {"host": platform.node(), "kernel": platform.release()}
+        for name, path in (("amdgpu", "/sys/module/amdgpu/version"), ("kfd_topology_nodes", "/sys/class/kfd/kfd/topology/generation_id")):
+            try:
+                info[name] = open(path).read().strip()
+            except OSError:
+                pass
+        info["torch_hip"] = getattr(torch.version, "hip", None)
+        info["device"] = torch.cuda.get_device_name(0)
+        try:
+            import steroscopic_hardware_amd as sha
+            d = sha.capi.device_describe(0)
+            info["pci"], info["numa_node"] = d["pci"], d["numa_node"]
+        except Exception as e:                                    # never fail a session over the banner
+            info["describe_error"] = repr(e)[:80]
+        try:
+            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showfwinfo"], capture_output=True, text=True, timeout=20).stdout
+            fw = {l.split(":")[0].split()[-2]: l.split(":")[-1].strip() for l in out.splitlines() if any(k in l for k in ("MEC firmware", "SDMA firmware", "SMC firmware", "VBIOS"))}
+            info["firmware"] = fw
+        except Exception:
+            pass
+        sys.stderr.write("[gpu box] " + " ".join(f"{k}={v}" for k, v in info.items()) + "\n")
+        sys.stderr.flush()
+    except Exception:
+        pass
+
+
 def _ensure_built():
     """Built artefacts are git-ignored: build whatever is missing (hipcc cross-compiles gfx950
     without a GPU), so a fresh checkout can run the suite directly."""

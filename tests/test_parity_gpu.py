@@ -919,24 +919,34 @@ def test_page_locked_batch_slot_reuse_and_failure_drains_the_streams(tmp_path):
 
 def test_host_register_refuses_overlapping_ranges():
     """the registry of page-locked ranges is sorted and DISJOINT (is_pinned looks at one predecessor, removal goes
-    by start address): a registration that overlaps a known range -- a sub-range of a sadhip_host_alloc block, a sub- or
-    super-range of an earlier registration -- is SADHIP_ERR_ARG and registers nothing."""
+    by start address) -- page by page, since page-locking works on whole pages: a registration that shares a page with a
+    known range -- a sub-range of a sadhip_host_alloc block, a sub- or super-range of an earlier registration, a neighbour
+    that begins inside its last page -- is SADHIP_ERR_ARG and registers nothing.  (All ranges here are page-aligned
+    multiples of a page inside one array that outlives every registration.)"""
     import ctypes
     l = capi.lib()
     with capi.HostBuffer(1 << 20) as hb:
         base = hb.view((1 << 20,)).ctypes.data
         for off, size in ((0, 4096), (8192, 4096), ((1 << 20) - 4096, 4096)):
             assert l.sadhip_host_register(ctypes.c_void_p(base + off), size) == capi.ERR_ARG, (off, size)
-    a = np.zeros(1 << 20, np.uint8)
-    p = a.ctypes.data
-    assert l.sadhip_host_register(ctypes.c_void_p(p + 65536), 262144) == capi.OK
-    for off, size in ((65536, 262144), (65536 + 4096, 4096), (0, 131072), (300000, 131072), (0, 1 << 20)):
-        assert l.sadhip_host_register(ctypes.c_void_p(p + off), size) == capi.ERR_ARG, (off, size)
-    assert l.sadhip_host_register(ctypes.c_void_p(p), 65536) == capi.OK                   # adjacent, not overlapping
-    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 4096)) == capi.ERR_ARG             # not the start of a range
+    a = np.zeros((1 << 20) + 8192, np.uint8)
+    p = (a.ctypes.data + 4095) & ~4095                                                     # page-aligned start inside a
+    PG = 4096
+    assert l.sadhip_host_register(ctypes.c_void_p(p + 16 * PG), 64 * PG) == capi.OK
+    for off, size in ((16 * PG, 64 * PG), (17 * PG, PG), (0, 32 * PG), (70 * PG, 32 * PG), (0, 200 * PG),
+                      (80 * PG - 100, PG), (15 * PG, PG + 1), (16 * PG - 1, 1 + 0)):      # the last three: only a page in common
+        expect = capi.OK if (off, size) == (16 * PG - 1, 1) else capi.ERR_ARG
+        got = l.sadhip_host_register(ctypes.c_void_p(p + off), size)
+        if (off, size) == (16 * PG - 1, 1):
+            assert got == capi.OK and l.sadhip_host_unregister(ctypes.c_void_p(p + off)) == capi.OK   # its page ends where the range begins
+        else:
+            assert got == expect, (off, size)
+    assert l.sadhip_host_register(ctypes.c_void_p(p), 16 * PG) == capi.OK                  # adjacent pages, nothing shared
+    assert l.sadhip_host_unregister(ctypes.c_void_p(p + PG)) == capi.ERR_ARG                # not the start of a range
     assert l.sadhip_host_unregister(ctypes.c_void_p(p)) == capi.OK
-    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 65536)) == capi.OK
-    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 65536)) == capi.ERR_ARG
+    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 16 * PG)) == capi.OK
+    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 16 * PG)) == capi.ERR_ARG
+    a[:] = 1                                                                                # the array is still ours
 
 
 def test_pool_workers_are_pinned_next_to_their_device():
