@@ -25,8 +25,10 @@
  * by an internal mutex.  Destroying a context while another thread is inside a call on it is a
  * use-after-free like in any C API: the bindings in INTEGRATION.md hold a reader lock across each
  * call.  Host pointers are never retained after a call returns, error returns included (cgo rule):
- * host buffers are copied with 2-D copies straight from / to the caller's memory on the context's
- * stream, and every host-buffer entry point waits for that stream before it returns.
+ * the host thread copies caller memory into / out of page-locked planes the context owns and only those
+ * are handed to the copy engines (caller memory inside page-locked ranges this library knows,
+ * sadhip_host_* below, is handed over as it is), and every host-buffer entry point waits for its
+ * stream before it returns.
  * sadhip_last_error() is thread-local: read it on the OS thread that made the failing call (a Go
  * caller wraps call + read in runtime.LockOSThread).
  * The library reads no environment variable (tuning knobs exist only in the diagnostics build
@@ -112,9 +114,10 @@ SADHIP_API const char* sadhip_last_error(void);                  /* thread-local
 
 /* ---- context ------------------------------------------------------------------------------
  * Replaces the worker pool of SetupConcurrentSAD (pkg/despair/sad.go:29-113): one context owns
- * the device planes (two frame slots), scratch and HIP streams for frames up to max_w x max_h.
+ * the device planes (three frame slots, each with page-locked host planes of the same size for
+ * caller memory that is not page-locked), scratch and HIP streams for frames up to max_w x max_h.
  * max_batch (>= 1) is a sizing hint kept for ABI stability: batches of ANY length stream through
- * the two slots.  Created when the Go shim's pipeline is set up, destroyed when its input channel
+ * the slots.  Created when the Go shim's pipeline is set up, destroyed when its input channel
  * is closed (sad.go:106-110, pkg/camera/output.go:213-220). */
 SADHIP_API int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch, sadhip_ctx** out);
 SADHIP_API int sadhip_ctx_destroy(sadhip_ctx* ctx);
@@ -167,12 +170,12 @@ SADHIP_API int sadhip_disparity_lr_u8(sadhip_ctx* ctx,
 
 /* ---- batch of independent frames, host buffers (synchronous; pipelined inside) --------------
  * Replaces the streaming loop of examples/run.stream.go:30-59 / BASELINE config 4: n independent
- * pairs (any n >= 0), H2D / kernel / D2H double-buffered on the context's two streams; copies go
- * straight from / to the caller's buffers (2-D copies), nothing is retained after return.
+ * pairs (any n >= 0), H2D / kernel / D2H pipelined over the context's three slots, a stream each (the host
+ * thread stages frame i+1 while frame i is on the device), nothing is retained after return.
  * When every frame of the batch lies in page-locked memory this library knows (sadhip_host_alloc /
  * sadhip_host_register below), the batch runs as groups of frames per kernel launch with truly
  * asynchronous linear copies (frames that follow each other in memory travel as one copy): the
- * PCIe-bound rate of pkg/camera's frame stream instead of the runtime's pageable staging. */
+ * PCIe-bound rate of pkg/camera's frame stream instead of the host thread's staging rate. */
 SADHIP_API int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
                               const uint8_t* const* lefts, const uint8_t* const* rights,
                               int w, int h, int lstride, int rstride,
@@ -212,7 +215,8 @@ SADHIP_API int sadhip_sad_windows_u8(sadhip_ctx* ctx,
 SADHIP_API int sadhip_gray_u8(sadhip_ctx* ctx, const uint8_t* pix, int channels,
                    int w, int h, int stride, uint8_t* gray, int gstride);
 
-/* RGBA/RGB pair in, disparity out: ONE upload per image (2-D copy from the caller's rows), gray
+/* RGBA/RGB pair in, disparity out: ONE upload per image (staged in ~2 MB bands, or one linear copy
+ * from page-locked memory this library knows), gray
  * conversion on the device into the context's planes, disparity kernel, one download -- no host
  * gray plane, no second H2D (what LoadPNG + RunSad cost separately). */
 SADHIP_API int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
@@ -251,8 +255,11 @@ SADHIP_API int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, 
 
 /* ---- page-locked host memory ---------------------------------------------------------------------
  * The reference hands the worker Go heap memory (image.Gray.Pix); a cgo callee may not keep such
- * pointers, so the host-buffer entry points copy from / to pageable memory through the HIP runtime's own
- * staging (about half the PCIe rate, and the host thread is busy while it happens).  A capture pipeline
+ * pointers, and memory the library did not lock itself is never handed to a copy engine (round 4: letting the
+ * HIP runtime lock the caller's pageable pages in place was 0.13 ms per 1080p call faster and ended a process
+ * with a GPU memory access fault on a host heap page three times in some twenty test-suite runs; DESIGN.md
+ * section 6b).  So the host-buffer entry points stage pageable memory through the context's own page-locked
+ * planes: about a third of the PCIe rate, and the host thread is busy while it happens.  A capture pipeline
  * (pkg/camera/serial.go fills a frame buffer per UART frame) or the C++ / Python host can keep its frames
  * in page-locked memory instead: sadhip_host_alloc returns hipHostMalloc'ed memory usable from every
  * device (a Go caller wraps it with unsafe.Slice as image.Gray.Pix -- C memory, not Go memory);
@@ -260,8 +267,7 @@ SADHIP_API int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, 
  * memory) until sadhip_host_unregister.  Every host-buffer entry point recognises pointers inside such
  * ranges and then uses asynchronous linear copies; results are identical either way.  Free / unregister a
  * range only when no call that was given pointers into it is still running (every entry point has finished
- * with the caller's memory when it returns); a range that disappears under a running call is not an error --
- * the copies fall back to the pageable path -- but its memory must of course stay valid.
+ * with the caller's memory when it returns).
  * The known ranges are DISJOINT page by page: sadhip_host_register of memory that shares a 4 KiB page with a sadhip_host_alloc
  * block or an earlier registration (a sub-range, a super-range, a partial overlap, a neighbour that starts or ends inside the
  * same page) returns SADHIP_ERR_ARG and registers nothing. */

@@ -353,18 +353,26 @@ class Context:
                                            out.ctypes.data if len(q) else None))
         return out
 
+    @staticmethod
+    def _pixel_rows(pix):
+        """A decoded picture as the ABI takes it: interleaved pixels, rows `strides[0]` bytes apart (image.NRGBA's Stride) -- a
+        sub-picture view is passed as it is, anything else is made contiguous first."""
+        if pix.ndim == 3 and pix.strides[2] == 1 and pix.strides[1] == pix.shape[2] and pix.strides[0] >= pix.shape[1] * pix.shape[2]:
+            return pix
+        return np.ascontiguousarray(pix)
+
     def gray(self, pix):
         if not isinstance(pix, np.ndarray) or pix.dtype != np.uint8 or pix.ndim != 3 or pix.shape[2] not in (3, 4):
             raise TypeError("pix: expected HxWx3 or HxWx4 uint8")
-        pix = np.ascontiguousarray(pix)
+        pix = self._pixel_rows(pix)
         h, w, c = pix.shape
         g = np.empty((h, w), np.uint8)
         _check(lib().sadhip_gray_u8(self._h, pix.ctypes.data, c, w, h, pix.strides[0], g.ctypes.data, g.strides[0]))
         return g
 
     def disparity_rgba(self, left_pix, right_pix, block, maxdisp, flags=0):
-        left_pix = np.ascontiguousarray(left_pix); right_pix = np.ascontiguousarray(right_pix)
         assert left_pix.shape == right_pix.shape and left_pix.dtype == np.uint8 and left_pix.ndim == 3
+        left_pix = self._pixel_rows(left_pix); right_pix = self._pixel_rows(right_pix)
         h, w, c = left_pix.shape
         out = np.empty((h, w), np.uint8)
         _check(lib().sadhip_disparity_rgba_u8(self._h, left_pix.ctypes.data, right_pix.ctypes.data, c, w, h,

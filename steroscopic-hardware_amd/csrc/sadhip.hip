@@ -18,6 +18,7 @@
 #include <new>
 #include <shared_mutex>
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -196,6 +197,120 @@ extern "C" int sadhip_host_unregister(void* p)
 }
 
 // ------------------------------------------------------------------------------------------
+// Copy gang: the host threads that move caller memory into / out of the context's page-locked planes.
+// One core copies frames that are not in its caches at 10-20 GB/s (tools/ab_hostcopy.py: 0.3-0.5 ms for
+// the 6 MB of a 1080p pair), a fraction of what the bus then moves; the helpers split the rows with the
+// calling thread.  The helpers touch host memory only -- no HIP call is made on them --
+// are started on the first large copy of a context and inherit the affinity of the thread that
+// starts them (a pool worker is pinned to the device's CPUs).
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct RowCopy {
+  uint8_t* dst; size_t dpitch; const uint8_t* src; size_t spitch; size_t wbytes;
+  bool whole_rows;           // the bytes between the rows may be copied too (dst is a plane of ours, src readable to its last row's wbytes)
+};
+
+static void copy_part(const RowCopy& c, int r0, int r1)
+{
+  if (r1 <= r0) return;
+  if (c.dpitch == c.spitch && (c.wbytes == c.dpitch || c.whole_rows)) {
+    memcpy(c.dst + (size_t)r0 * c.dpitch, c.src + (size_t)r0 * c.spitch, (size_t)(r1 - r0 - 1) * c.dpitch + c.wbytes);
+    return;
+  }
+  for (int r = r0; r < r1; ++r) memcpy(c.dst + (size_t)r * c.dpitch, c.src + (size_t)r * c.spitch, c.wbytes);
+}
+
+class CopyGang {
+ public:
+  static constexpr size_t kMinBytes = (size_t)512 << 10;      // below this the calling thread copies alone
+  static constexpr int kSpinUs = 150;   // a helper polls this long for the next piece before it sleeps (L, R and the result of a
+                                        // call follow each other within that; waking a sleeping core costs 20-50 us per piece)
+  explicit CopyGang(int helpers) : helpers_(helpers) {}
+  ~CopyGang()
+  {
+    { std::lock_guard<std::mutex> lk(mu_); stop_.store(true, std::memory_order_release); }
+    cv_work_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void rows(const RowCopy& c, int r0, int r1)
+  {
+    const int n = r1 - r0;
+    if (helpers_ <= 0 || n < 2 * (helpers_ + 1) || (size_t)n * c.wbytes < kMinBytes || !start()) { copy_part(c, r0, r1); return; }
+    const int parts = helpers_ + 1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);                     // (the increment under the lock: no helper misses its wake-up)
+      job_ = c; j0_ = r0; j1_ = r1;
+      pending_.store(helpers_, std::memory_order_relaxed);
+      gen_.fetch_add(1, std::memory_order_release);
+    }
+    cv_work_.notify_all();
+    copy_part(c, r0 + (int)((long long)n * helpers_ / parts), r1);          // the caller's own share: the last one
+    if (!spin_until([&] { return pending_.load(std::memory_order_acquire) == 0; })) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+    }
+  }
+
+ private:
+  template <class F> static bool spin_until(F&& done)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0;; ++i) {
+      if (done()) return true;
+      __builtin_ia32_pause();
+      if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) return false;
+    }
+  }
+  bool start()
+  {
+    if (!th_.empty()) return true;
+    if (failed_) return false;
+    try {
+      for (int k = 0; k < helpers_; ++k) th_.emplace_back([this, k] { work(k); });
+    } catch (...) {                                            // no threads to be had: the caller copies alone
+      { std::lock_guard<std::mutex> lk(mu_); stop_.store(true, std::memory_order_release); }
+      cv_work_.notify_all();
+      for (auto& t : th_) t.join();
+      th_.clear(); stop_.store(false, std::memory_order_release); failed_ = true;
+      return false;
+    }
+    return true;
+  }
+  void work(int k)
+  {
+    unsigned seen = 0;
+    for (;;) {
+      auto news = [&] { return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen; };
+      if (!spin_until(news)) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_work_.wait(lk, news);
+      }
+      if (stop_.load(std::memory_order_acquire)) return;
+      seen = gen_.load(std::memory_order_acquire);
+      const RowCopy c = job_; const int r0 = j0_, r1 = j1_;   // stable until every helper has reported (rows() waits for that)
+      const int n = r1 - r0, parts = helpers_ + 1;
+      copy_part(c, r0 + (int)((long long)n * k / parts), r0 + (int)((long long)n * (k + 1) / parts));
+      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        { std::lock_guard<std::mutex> lk(mu_); }              // the caller is either polling or inside wait(): never in between
+        cv_done_.notify_one();
+      }
+    }
+  }
+  const int helpers_;
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  RowCopy job_{}; int j0_ = 0, j1_ = 0;
+  std::atomic<unsigned> gen_{0};
+  std::atomic<int> pending_{0};
+  std::atomic<bool> stop_{false};
+  bool failed_ = false;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -205,6 +320,11 @@ struct Slot {            // one pipeline stage worth of buffers (one frame)
   uint8_t *dL = nullptr, *dR = nullptr, *dO = nullptr;   // device planes
   hipStream_t stream = nullptr;
   hipEvent_t k0 = nullptr, k1 = nullptr;                 // kernel begin / end
+  static constexpr int kMaxBands = 4;
+  hipEvent_t band[kMaxBands] = {};                       // band b of a staged result has arrived in hO
+  uint8_t* out = nullptr; int ostride = 0;               // where the frame in flight delivers (route_output)
+  bool out_direct = false;                               // ... straight into the caller's (page-locked) memory
+  int out_bands = 1;
 };
 
 struct sadhip_ctx {
@@ -212,7 +332,11 @@ struct sadhip_ctx {
   int max_w = 0, max_h = 0, max_batch = 0;
   size_t pitch = 0;            // bytes per row of the staging planes
   size_t plane = 0;            // bytes per staging plane
-  static constexpr int kSlots = 2;
+#ifdef SADHIP_SLOTS
+  static constexpr int kSlots = SADHIP_SLOTS;
+#else
+  static constexpr int kSlots = 3;
+#endif
   Slot slot[kSlots];
   // Batches whose frames all lie in page-locked memory (sadhip_host_*) run through these instead: kGroup frames per
   // kernel launch, asynchronous linear copies, and ONE STREAM PER DIRECTION -- uploads, kernels and downloads each have
@@ -231,13 +355,26 @@ struct sadhip_ctx {
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* h_scratch = nullptr; size_t h_scratch_bytes = 0;
   float last_kernel_ms = 0.f, last_total_ms = 0.f;
-  // Host copies: hipMemcpy2DAsync straight from / to the caller's (pageable) buffers -- the
-  // runtime's own staging measured 2.2x faster than memcpy into pinned planes + linear copies
-  // (0.27 vs 0.58 ms per 1080p pair; 6 700 vs 2 900 pairs/s pipelined).  Every host entry point
-  // synchronises its stream before returning -- on error exits too -- so no caller pointer
-  // outlives the call.  The pinned-plane path survives only in the diagnostics build
-  // (-DSADHIP_TUNING, SADHIP_PINNED_STAGING=1) for comparison; the product reads no environment.
-  bool pinned_staging = false;
+  // Host copies.  A caller buffer inside page-locked memory this library knows (sadhip_host_alloc / _register /
+  // sadhip_pool_host_alloc) is handed to the copy engines as it is.  ANY OTHER host memory is copied by the host thread
+  // into / out of the slot's own page-locked planes (hL, hR, hO), in bands so that the memcpy of one band overlaps the bus
+  // transfer of the one before; no device-side copy ever touches memory the library did not lock itself.  Rounds 2-4
+  // handed pageable caller memory to hipMemcpy2DAsync (the runtime locks the caller's pages in place: 0.14 ms instead of
+  // 0.28 ms for the two uploads of a 1080p pair, tools/ubench/h2d_paths.hip); round 4 saw that path end a process with
+  // "Memory access fault by GPU ... on address <a host heap page>" three times in some twenty full test runs (DESIGN.md
+  // section 6b), so it survives only in the diagnostics build (-DSADHIP_TUNING, SADHIP_TUNE_HOSTCOPY=direct) for comparison.
+  // Every host entry point synchronises its stream before returning -- on error exits too.
+  // Staged copies are split two ways (tools/ab_hostcopy.py, profiles/r04_ab_hostcopy.txt; 1080p, BlockSize 9, MaxDisparity 64):
+  // across kCopyHelpers + 1 host threads (CopyGang above) -- one thread: 0.39 ms per call on a pair that is in the caches,
+  // 0.79 on 64 different pairs, 2 340 pairs/s batched; six threads: 0.27 / 0.30 ms, 7 600 pairs/s (the withdrawn in-place
+  // path: 0.20 / 0.36 ms, 4 900 pairs/s) -- and into bands of about band_bytes, so that the bus moves band b while the
+  // threads copy band b+1.  With the gang a band below 8 MB no longer pays (each costs a copy call and a gang hand-off:
+  // sadhip_disparity_rgba_u8 0.55 ms at 8 MB, 0.63 at 2 MB): a 1080p plane or decoded picture goes in one piece, a 4K
+  // RGBA picture in four.
+  bool direct_pageable = false;
+  size_t band_bytes = (size_t)8 << 20;
+  static constexpr int kCopyHelpers = 5;       // + the calling thread
+  std::unique_ptr<CopyGang> gang;
   std::mutex mu;
 };
 
@@ -275,6 +412,7 @@ static void destroy_ctx(sadhip_ctx* c)
     if (s.dO) (void)hipFree(s.dO);
     if (s.k0) (void)hipEventDestroy(s.k0);
     if (s.k1) (void)hipEventDestroy(s.k1);
+    for (auto& b : s.band) if (b) (void)hipEventDestroy(b);
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -343,18 +481,23 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
   c->pitch = align_up((size_t)max_w, 256);
   c->plane = c->pitch * (size_t)max_h;
 #ifdef SADHIP_TUNING
-  c->pinned_staging = getenv("SADHIP_PINNED_STAGING") != nullptr;
+  if (const char* e = getenv("SADHIP_TUNE_HOSTCOPY")) c->direct_pageable = strcmp(e, "direct") == 0;
+  if (const char* e = getenv("SADHIP_TUNE_BANDKB")) c->band_bytes = (size_t)std::max(atoi(e), 4) << 10;
+  int helpers = sadhip_ctx::kCopyHelpers;
+  if (const char* e = getenv("SADHIP_TUNE_COPYTHREADS")) helpers = std::min(std::max(atoi(e), 1), 32) - 1;
+  c->gang.reset(new (std::nothrow) CopyGang(helpers));
+#else
+  c->gang.reset(new (std::nothrow) CopyGang(sadhip_ctx::kCopyHelpers));
 #endif
   for (auto& s : c->slot) {
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&s.k0);
     if (e == hipSuccess) e = hipEventCreate(&s.k1);
-    if (c->pinned_staging) {
-      if (e == hipSuccess) e = hipHostMalloc((void**)&s.hL, c->plane, hipHostMallocDefault);
-      if (e == hipSuccess) e = hipHostMalloc((void**)&s.hR, c->plane, hipHostMallocDefault);
-      if (e == hipSuccess) e = hipHostMalloc((void**)&s.hO, c->plane, hipHostMallocDefault);
-    }
+    for (auto& b : s.band) if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hL, c->plane, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hR, c->plane, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hO, c->plane, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dL, c->plane);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dR, c->plane);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dO, c->plane);
@@ -450,24 +593,54 @@ extern "C" int sadhip_kernel_kind(int w, int h, int block, int maxdisp, unsigned
   return fast_supported(j) ? KIND_COLWAVE : generic;
 }
 
-// copy rows [r0,r1) of a host image (stride) into compact staging rows (pitch), staging row 0 = r0
-static void stage_rows(uint8_t* dst, size_t pitch, const uint8_t* src, int stride, int w, int r0, int r1)
-{
-  if (r1 <= r0) return;
-  if ((size_t)stride == pitch) {   // contiguous: one copy (last row only w bytes: never read past the image)
-    memcpy(dst, src + (size_t)r0 * stride, (size_t)(r1 - r0 - 1) * pitch + (size_t)w);
-    return;
-  }
-  for (int r = r0; r < r1; ++r) memcpy(dst + (size_t)(r - r0) * pitch, src + (size_t)r * stride, (size_t)w);
-}
-
 using clk = std::chrono::steady_clock;
 
-// One frame (or band of a frame) through slot s: stage -> H2D -> kernel -> D2H, all async on
-// the slot's stream.  rows [band0,band1) of the inputs are uploaded.
 // row pitch of the staging planes for a w-wide frame (<= the context's allocation pitch)
 static inline size_t pitch_for(int w) { return align_up((size_t)w, 256); }
 
+// rows of `pitch` bytes cut into bands of whole rows, about band_bytes each (at most Slot::kMaxBands, none shorter than 64 rows)
+static inline int band_count(int rows, size_t pitch, size_t band_bytes)
+{
+  const size_t want = ((size_t)rows * pitch + band_bytes / 2) / band_bytes;
+  return (int)std::max<size_t>(1, std::min<size_t>({want, (size_t)Slot::kMaxBands, (size_t)rows / 64}));
+}
+static inline int band_row(int r0, int r1, int nb, int b) { return r0 + (int)((long long)(r1 - r0) * b / nb); }
+
+static inline void copy_rows(sadhip_ctx* c, const RowCopy& rc, int rows)
+{
+  if (c->gang) c->gang->rows(rc, 0, rows); else copy_part(rc, 0, rows);
+}
+
+// Rows [r0, r1) of a host image that is NOT in page-locked memory this library knows -> device rows of `pitch` bytes
+// (device row 0 = image row r0), through the page-locked plane `stage`: the host thread copies a band, queues its transfer
+// and copies the next band while the first is on the bus.
+static int upload_staged(sadhip_ctx* c, hipStream_t st, uint8_t* dev, uint8_t* stage, size_t pitch,
+                         const uint8_t* src, size_t stride, size_t wbytes, int r0, int r1)
+{
+  const int nb = band_count(r1 - r0, pitch, c->band_bytes);
+  for (int b = 0; b < nb; ++b) {
+    const int a0 = band_row(r0, r1, nb, b), a1 = band_row(r0, r1, nb, b + 1);
+    if (a1 <= a0) continue;
+    uint8_t* hb = stage + (size_t)(a0 - r0) * pitch;
+    // stage row 0 of the band = image row a0; never a byte past an image row's wbytes on the last row of a part
+    copy_rows(c, RowCopy{hb, pitch, src + (size_t)a0 * stride, stride, wbytes, true}, a1 - a0);
+    HIPTRY(hipMemcpyAsync(dev + (size_t)(a0 - r0) * pitch, hb, (size_t)(a1 - a0) * pitch, hipMemcpyHostToDevice, st));
+  }
+  return SADHIP_OK;
+}
+
+// Where the result of the frame about to be queued on slot s goes: straight into the caller's rows when they lie in
+// page-locked memory this library knows, through the slot's page-locked plane otherwise.  Call before enqueue_frame.
+static void route_output(sadhip_ctx* c, Slot& s, uint8_t* out, int ostride, int wbytes, int rows)
+{
+  s.out = out; s.ostride = ostride;
+  s.out_direct = c->direct_pageable || is_pinned(out, (size_t)(rows - 1) * ostride + wbytes);
+}
+
+static int enqueue_download(sadhip_ctx* c, Slot& s, int w, int x0, int x1, int rows);
+
+// One frame (or band of a frame) through slot s: upload -> kernel -> download, all async on the slot's stream.  Rows
+// [band0,band1) of the inputs are uploaded.
 // rw, rh: the part of the right image that exists (<= w, h; == w, h unless the caller's right image is the smaller
 // one, sadhip_disparity_lr_u8): only that part is read from the caller's memory.
 static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint8_t* right,
@@ -475,31 +648,27 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
                          int x0, int y0, int x1, int y1, int band0, int band1, int rw = 0, int rh = 0)
 {
   const size_t pitch = pitch_for(w);
-  const bool direct = !c->pinned_staging;   // default: 2-D copies straight from / to the caller's memory
   if (rw <= 0 || rw > w) rw = w;
   if (rh <= 0 || rh > h) rh = h;
   const int rband1 = band1 < rh ? band1 : rh;             // right rows [band0, rband1) exist
   // Page-locked inputs this library knows (sadhip_host_*): one asynchronous linear copy per image, the device rows
-  // keep the caller's stride (the runtime stages nothing and the host thread does not wait for the bus).
+  // keep the caller's stride (nothing is staged and the host thread does not wait for the bus).
   size_t dl = pitch, dr = pitch;                           // device row strides
   const size_t lbytes = (size_t)(band1 - band0 - 1) * lstride + w;
   const size_t rbytes = rband1 > band0 ? (size_t)(rband1 - band0 - 1) * rstride + rw : 0;
-  const bool pinned = direct && (size_t)lstride * (band1 - band0) <= c->plane && (size_t)rstride * (band1 - band0) <= c->plane &&
+  const bool pinned = (size_t)lstride * (band1 - band0) <= c->plane && (size_t)rstride * (band1 - band0) <= c->plane &&
                       is_pinned(left + (size_t)band0 * lstride, lbytes) && (rbytes == 0 || is_pinned(right + (size_t)band0 * rstride, rbytes));
   if (pinned) {
     dl = (size_t)lstride; dr = (size_t)rstride;
     HIPTRY(hipMemcpyAsync(s.dL, left + (size_t)band0 * lstride, lbytes, hipMemcpyHostToDevice, s.stream));
     if (rbytes) HIPTRY(hipMemcpyAsync(s.dR, right + (size_t)band0 * rstride, rbytes, hipMemcpyHostToDevice, s.stream));
-  } else if (direct) {
+  } else if (c->direct_pageable) {                         // diagnostics build only: the runtime locks the caller's pages
     HIPTRY(hipMemcpy2DAsync(s.dL, pitch, left + (size_t)band0 * lstride, lstride, w, band1 - band0, hipMemcpyHostToDevice, s.stream));
     if (rband1 > band0)
       HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, rw, rband1 - band0, hipMemcpyHostToDevice, s.stream));
   } else {
-  stage_rows(s.hL, pitch, left, lstride, w, band0, band1);
-  stage_rows(s.hR, pitch, right, rstride, rw, band0, rband1);
-  const size_t bytes = (size_t)(band1 - band0) * pitch;
-  HIPTRY(hipMemcpyAsync(s.dL, s.hL, bytes, hipMemcpyHostToDevice, s.stream));
-  HIPTRY(hipMemcpyAsync(s.dR, s.hR, bytes, hipMemcpyHostToDevice, s.stream));
+    if (int st = upload_staged(c, s.stream, s.dL, s.hL, pitch, left, (size_t)lstride, (size_t)w, band0, band1)) return st;
+    if (int st = upload_staged(c, s.stream, s.dR, s.hR, pitch, right, (size_t)rstride, (size_t)rw, band0, rband1)) return st;
   }
   Job j{};
   j.left = s.dL; j.right = s.dR; j.out = s.dO;
@@ -514,25 +683,44 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
   HIPTRY(hipEventRecord(s.k0, s.stream));
   HIPTRY(dispatch(j, flags, s.stream));
   HIPTRY(hipEventRecord(s.k1, s.stream));
-  if (!direct) HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)(y1 - y0) * pitch, hipMemcpyDeviceToHost, s.stream));
+  return enqueue_download(c, s, w, x0, x1, y1 - y0);
+}
+
+// queue the download of result rows [0, rows) of slot s (after its kernel): into the caller's page-locked rows, or into
+// the slot's page-locked plane band by band (finish_frame copies each band out as it arrives)
+static int enqueue_download(sadhip_ctx* c, Slot& s, int w, int x0, int x1, int rows)
+{
+  const size_t pitch = pitch_for(w);
+  if (s.out_direct) {
+    HIPTRY(hipMemcpy2DAsync(s.out, s.ostride, s.dO + x0, pitch, x1 - x0, rows, hipMemcpyDeviceToHost, s.stream));
+    return SADHIP_OK;
+  }
+  s.out_bands = band_count(rows, pitch, c->band_bytes);
+  for (int b = 0; b < s.out_bands; ++b) {
+    const int a0 = band_row(0, rows, s.out_bands, b), a1 = band_row(0, rows, s.out_bands, b + 1);
+    HIPTRY(hipMemcpyAsync(s.hO + (size_t)a0 * pitch, s.dO + (size_t)a0 * pitch, (size_t)(a1 - a0) * pitch, hipMemcpyDeviceToHost, s.stream));
+    HIPTRY(hipEventRecord(s.band[b], s.stream));
+  }
   return SADHIP_OK;
 }
 
-static int finish_frame(sadhip_ctx* c, Slot& s, int w, int x0, int y0, int x1, int y1, uint8_t* out, int ostride,
-                        float* kernel_ms)
+// wait for the frame queued on slot s and hand a staged result to the caller's rows (s.out, route_output)
+static int finish_frame(sadhip_ctx* c, Slot& s, int w, int x0, int y0, int x1, int y1, float* kernel_ms)
 {
   const size_t pitch = pitch_for(w);
-  const bool direct = !c->pinned_staging;
-  if (direct)
-    HIPTRY(hipMemcpy2DAsync(out, ostride, s.dO + x0, pitch, x1 - x0, y1 - y0, hipMemcpyDeviceToHost, s.stream));
+  const int rows = y1 - y0, rw = x1 - x0;
+  uint8_t* out = s.out; const int ostride = s.ostride;
+  if (!s.out_direct)
+    for (int b = 0; b < s.out_bands; ++b) {
+      HIPTRY(hipEventSynchronize(s.band[b]));
+      const int a0 = band_row(0, rows, s.out_bands, b), a1 = band_row(0, rows, s.out_bands, b + 1);
+      // never a byte outside the caller's rw-byte rows
+      copy_rows(c, RowCopy{out + (size_t)a0 * ostride, (size_t)ostride, s.hO + (size_t)a0 * pitch + x0, pitch, (size_t)rw, false}, a1 - a0);
+    }
   HIPTRY(hipStreamSynchronize(s.stream));
   float ms = 0.f;
   HIPTRY(hipEventElapsedTime(&ms, s.k0, s.k1));
   if (kernel_ms) *kernel_ms += ms;
-  const int rw = x1 - x0;
-  if (!direct)
-    for (int r = 0; r < y1 - y0; ++r)
-      memcpy(out + (size_t)r * ostride, s.hO + (size_t)r * pitch + x0, (size_t)rw);
   return SADHIP_OK;
 }
 
@@ -555,8 +743,9 @@ extern "C" int sadhip_disparity_region_u8(sadhip_ctx* ctx, const uint8_t* left, 
   const int band1 = y1 + hs > h ? h : y1 + hs;
   Slot& s = ctx->slot[0];
   float kms = 0.f;
+  route_output(ctx, s, out_region, x1 - x0, x1 - x0, y1 - y0);
   int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags, x0, y0, x1, y1, band0, band1);
-  if (st == SADHIP_OK) st = finish_frame(ctx, s, w, x0, y0, x1, y1, out_region, x1 - x0, &kms);
+  if (st == SADHIP_OK) st = finish_frame(ctx, s, w, x0, y0, x1, y1, &kms);
   if (st != SADHIP_OK) { (void)hipStreamSynchronize(s.stream); return st; }   // no copy from/to caller memory left in flight
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
@@ -594,8 +783,9 @@ extern "C" int sadhip_disparity_lr_u8(sadhip_ctx* ctx,
   const int band1 = y1 + hs > lh ? lh : y1 + hs;
   Slot& s = ctx->slot[0];
   float kms = 0.f;
+  route_output(ctx, s, out, ostride, x1 - x0, y1 - y0);
   int st = enqueue_frame(ctx, s, left, right, lw, lh, lstride, rstride, block, maxdisp, flags, x0, y0, x1, y1, band0, band1, rw, rh);
-  if (st == SADHIP_OK) st = finish_frame(ctx, s, lw, x0, y0, x1, y1, out, ostride, &kms);
+  if (st == SADHIP_OK) st = finish_frame(ctx, s, lw, x0, y0, x1, y1, &kms);
   if (st != SADHIP_OK) { (void)hipStreamSynchronize(s.stream); return st; }
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
@@ -616,8 +806,9 @@ extern "C" int sadhip_disparity_u8(sadhip_ctx* ctx, const uint8_t* left, const u
   const auto t0 = clk::now();
   Slot& s = ctx->slot[0];
   float kms = 0.f;
+  route_output(ctx, s, out, ostride, w, h);
   int st = enqueue_frame(ctx, s, left, right, w, h, lstride, rstride, block, maxdisp, flags, 0, 0, w, h, 0, h);
-  if (st == SADHIP_OK) st = finish_frame(ctx, s, w, 0, 0, w, h, out, ostride, &kms);
+  if (st == SADHIP_OK) st = finish_frame(ctx, s, w, 0, 0, w, h, &kms);
   if (st != SADHIP_OK) { (void)hipStreamSynchronize(s.stream); return st; }
   ctx->last_kernel_ms = kms;
   ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
@@ -736,7 +927,7 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
   float kms = 0.f;
   {
     // every frame in page-locked memory this library knows, frames fit the device planes at the caller's strides
-    bool pinned = !ctx->pinned_staging && (size_t)lstride * h <= ctx->plane && (size_t)rstride * h <= ctx->plane &&
+    bool pinned = (size_t)lstride * h <= ctx->plane && (size_t)rstride * h <= ctx->plane &&
                   (size_t)ostride * h <= ctx->plane;
     const size_t cl = (size_t)lstride * (h - 1) + w, cr = (size_t)rstride * (h - 1) + w, co = (size_t)ostride * (h - 1) + w;
     for (int i = 0; i < n && pinned; ++i)
@@ -748,8 +939,9 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
       return SADHIP_OK;
     }
   }
-  // two-slot software pipeline: while slot A's frame is on the GPU, the host stages and
-  // enqueues the next frame on slot B, then drains A.
+  // software pipeline over the kSlots slots: while earlier frames are on the bus / the GPU, the host stages and
+  // enqueues the next frame on a free slot, then drains the oldest (two slots left the host waiting for the GPU
+  // 75 us per pair: profiles/r04_ab_hostcopy_2slots.txt against r04_ab_hostcopy.txt).
 #ifdef SADHIP_TUNING
   static const bool seq = getenv("SADHIP_BATCH_SEQ") != nullptr;      // tuning aid: no cross-frame overlap
 #else
@@ -757,8 +949,9 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
 #endif
   if (seq) {
     for (int i = 0; i < n; ++i) {
+      route_output(ctx, ctx->slot[0], outs[i], ostride, w, h);
       if (int st = enqueue_frame(ctx, ctx->slot[0], lefts[i], rights[i], w, h, lstride, rstride, block, maxdisp, flags, 0, 0, w, h, 0, h)) return st;
-      if (int st = finish_frame(ctx, ctx->slot[0], w, 0, 0, w, h, outs[i], ostride, &kms)) return st;
+      if (int st = finish_frame(ctx, ctx->slot[0], w, 0, 0, w, h, &kms)) return st;
     }
     ctx->last_kernel_ms = kms;
     ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
@@ -767,6 +960,7 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
   constexpr int S = sadhip_ctx::kSlots;
   for (int i = 0; i < n + S - 1; ++i) {
     if (i < n) {
+      route_output(ctx, ctx->slot[i % S], outs[i], ostride, w, h);
       if (int st = enqueue_frame(ctx, ctx->slot[i % S], lefts[i], rights[i], w, h, lstride, rstride,
                                  block, maxdisp, flags, 0, 0, w, h, 0, h)) {
         for (auto& s : ctx->slot) (void)hipStreamSynchronize(s.stream);
@@ -775,7 +969,7 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
     }
     const int d = i - (S - 1);
     if (d >= 0) {
-      if (int st = finish_frame(ctx, ctx->slot[d % S], w, 0, 0, w, h, outs[d], ostride, &kms)) {
+      if (int st = finish_frame(ctx, ctx->slot[d % S], w, 0, 0, w, h, &kms)) {
         for (auto& s : ctx->slot) (void)hipStreamSynchronize(s.stream);
         return st;
       }
@@ -891,6 +1085,26 @@ static int check_pix(const uint8_t* pix, int channels, int w, int h, int stride)
   return SADHIP_OK;
 }
 
+// one decoded picture (w x h pixels of `channels` bytes) -> device rows; returns the device row stride in *dstride.
+// Page-locked memory this library knows: one linear copy, the device rows keep the caller's stride (dev holds cap
+// bytes).  Anything else: through the page-locked plane `stage` (upload_staged), compact rows of prow bytes.
+static int upload_pix(sadhip_ctx* c, hipStream_t st, uint8_t* dev, size_t cap, uint8_t* stage, size_t prow,
+                      const uint8_t* pix, int channels, int w, int h, int stride, size_t* dstride)
+{
+  const size_t wbytes = (size_t)w * channels, span = (size_t)(h - 1) * stride + wbytes;
+  if ((size_t)stride * h <= cap && is_pinned(pix, span)) {
+    HIPTRY(hipMemcpyAsync(dev, pix, span, hipMemcpyHostToDevice, st));
+    *dstride = (size_t)stride;
+    return SADHIP_OK;
+  }
+  *dstride = prow;
+  if (c->direct_pageable) {                                  // diagnostics build only
+    HIPTRY(hipMemcpy2DAsync(dev, prow, pix, (size_t)stride, wbytes, h, hipMemcpyHostToDevice, st));
+    return SADHIP_OK;
+  }
+  return upload_staged(c, st, dev, stage, prow, pix, (size_t)stride, wbytes, 0, h);
+}
+
 extern "C" int sadhip_gray_u8(sadhip_ctx* ctx, const uint8_t* pix, int channels,
                               int w, int h, int stride, uint8_t* gray, int gstride)
 {
@@ -899,25 +1113,30 @@ extern "C" int sadhip_gray_u8(sadhip_ctx* ctx, const uint8_t* pix, int channels,
   if (gstride < w) return fail(SADHIP_ERR_STRIDE, "gstride=%d w=%d", gstride, w);
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPTRY(hipSetDevice(ctx->device));
-  const size_t prow = align_up((size_t)w * channels, 16), pbytes = prow * h;
-  const size_t grow = align_up((size_t)w, 16), gbytes = grow * h;
-  const size_t off_g = align_up(pbytes, 256);
-  if (int st = ensure_scratch(ctx, off_g + gbytes, 0)) return st;
-  uint8_t* ds = (uint8_t*)ctx->d_scratch;
+  const size_t prow = align_up((size_t)w * channels, 16);
+  const size_t pcap = align_up(std::max(prow, (size_t)stride) * h, 256);      // the picture at either row stride
+  const size_t grow = align_up((size_t)w, 16), gbytes = align_up(grow * h, 256);
+  if (int st = ensure_scratch(ctx, pcap + gbytes, pcap + gbytes)) return st;
+  uint8_t* ds = (uint8_t*)ctx->d_scratch; uint8_t* hs = (uint8_t*)ctx->h_scratch;
   hipStream_t s = ctx->slot[0].stream;
   return synced_on_error(s, [&]() -> int {
-    // one 2-D copy per direction straight from / to the caller's rows (no host staging copy)
-    HIPTRY(hipMemcpy2DAsync(ds, prow, pix, (size_t)stride, (size_t)w * channels, h, hipMemcpyHostToDevice, s));
-    HIPTRY(launch_gray(ds, channels, w, h, (int)prow, ds + off_g, (int)grow, s));
-    HIPTRY(hipMemcpy2DAsync(gray, (size_t)gstride, ds + off_g, grow, (size_t)w, h, hipMemcpyDeviceToHost, s));
+    size_t dstride = 0;
+    if (int st = upload_pix(ctx, s, ds, pcap, hs, prow, pix, channels, w, h, stride, &dstride)) return st;
+    HIPTRY(launch_gray(ds, channels, w, h, (int)dstride, ds + pcap, (int)grow, s));
+    if (ctx->direct_pageable || is_pinned(gray, (size_t)(h - 1) * gstride + w)) {
+      HIPTRY(hipMemcpy2DAsync(gray, (size_t)gstride, ds + pcap, grow, (size_t)w, h, hipMemcpyDeviceToHost, s));
+      HIPTRY(hipStreamSynchronize(s));
+      return SADHIP_OK;
+    }
+    HIPTRY(hipMemcpyAsync(hs + pcap, ds + pcap, grow * h, hipMemcpyDeviceToHost, s));
     HIPTRY(hipStreamSynchronize(s));
+    copy_rows(ctx, RowCopy{gray, (size_t)gstride, hs + pcap, grow, (size_t)w, false}, h);
     return SADHIP_OK;
   });
 }
 
-// RGBA/RGB pair in, disparity out.  One upload per image (2-D copy from the caller's rows into
-// device scratch), gray conversion into the slot's device planes, disparity kernel, one download:
-// no host gray plane and no second H2D.
+// RGBA/RGB pair in, disparity out.  One upload per image into device scratch, gray conversion into the slot's device
+// planes, disparity kernel, one download: no host gray plane and no second H2D.
 extern "C" int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
                                         const uint8_t* left_pix, const uint8_t* right_pix, int channels,
                                         int w, int h, int lstride, int rstride,
@@ -934,18 +1153,21 @@ extern "C" int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPTRY(hipSetDevice(ctx->device));
   const auto t0 = clk::now();
-  const size_t prow = align_up((size_t)w * channels, 16), pbytes = align_up(prow * h, 256);
-  if (int st = ensure_scratch(ctx, 2 * pbytes, 0)) return st;
-  uint8_t* ds = (uint8_t*)ctx->d_scratch;
+  const size_t prow = align_up((size_t)w * channels, 16);
+  const size_t pcap = align_up(std::max({prow, (size_t)lstride, (size_t)rstride}) * h, 256);
+  if (int st = ensure_scratch(ctx, 2 * pcap, 2 * pcap)) return st;
+  uint8_t* ds = (uint8_t*)ctx->d_scratch; uint8_t* hs = (uint8_t*)ctx->h_scratch;
   Slot& s = ctx->slot[0];
   float kms = 0.f;
+  route_output(ctx, s, out, ostride, w, h);
   const int st = synced_on_error(s.stream, [&]() -> int {
-    HIPTRY(hipMemcpy2DAsync(ds, prow, left_pix, (size_t)lstride, (size_t)w * channels, h, hipMemcpyHostToDevice, s.stream));
-    HIPTRY(hipMemcpy2DAsync(ds + pbytes, prow, right_pix, (size_t)rstride, (size_t)w * channels, h, hipMemcpyHostToDevice, s.stream));
+    size_t dls = 0, drs = 0;
+    if (int e = upload_pix(ctx, s.stream, ds, pcap, hs, prow, left_pix, channels, w, h, lstride, &dls)) return e;
+    if (int e = upload_pix(ctx, s.stream, ds + pcap, pcap, hs + pcap, prow, right_pix, channels, w, h, rstride, &drs)) return e;
     HIPTRY(hipEventRecord(s.k0, s.stream));
     const size_t gpitch = pitch_for(w);
-    HIPTRY(launch_gray(ds, channels, w, h, (int)prow, s.dL, (int)gpitch, s.stream));
-    HIPTRY(launch_gray(ds + pbytes, channels, w, h, (int)prow, s.dR, (int)gpitch, s.stream));
+    HIPTRY(launch_gray(ds, channels, w, h, (int)dls, s.dL, (int)gpitch, s.stream));
+    HIPTRY(launch_gray(ds + pcap, channels, w, h, (int)drs, s.dR, (int)gpitch, s.stream));
     Job j{};
     j.left = s.dL; j.right = s.dR; j.out = s.dO;
     j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = ctx->plane;
@@ -955,8 +1177,8 @@ extern "C" int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
     j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
     HIPTRY(dispatch(j, flags, s.stream));
     HIPTRY(hipEventRecord(s.k1, s.stream));
-    if (ctx->pinned_staging) HIPTRY(hipMemcpyAsync(s.hO, s.dO, (size_t)h * gpitch, hipMemcpyDeviceToHost, s.stream));
-    return finish_frame(ctx, s, w, 0, 0, w, h, out, ostride, &kms);
+    if (int e = enqueue_download(ctx, s, w, 0, w, h)) return e;
+    return finish_frame(ctx, s, w, 0, 0, w, h, &kms);
   });
   if (st != SADHIP_OK) return st;
   ctx->last_kernel_ms = kms;

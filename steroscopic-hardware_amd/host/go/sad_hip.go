@@ -105,8 +105,9 @@ func (c *hipCtx) with(w, h int, fn func(*C.sadhip_ctx) error) error {
 }
 
 // regionHIP computes one chunk on the device.  Go pointers are only borrowed for the call
-// (libsadhip copies from / to them with 2-D copies and waits for its stream before returning,
-// also on errors), as cgo requires.
+// (libsadhip's host thread copies them into / out of page-locked planes of its own -- no device-side
+// copy ever touches Go memory -- and has finished with them when it returns, also on errors), as
+// cgo requires.
 func regionHIP(left, right *image.Gray, p Parameters, r image.Rectangle) ([]uint8, error) {
 	data := make([]uint8, r.Dx()*r.Dy())
 	if len(data) == 0 {
@@ -227,7 +228,7 @@ func rgba8(img image.Image) (pix []uint8, stride int, ok bool) {
 	return nil, 0, false
 }
 
-// imagesHIP is one sadhip_disparity_rgba_u8 call: one upload per picture (2-D copies from the pictures' own rows),
+// imagesHIP is one sadhip_disparity_rgba_u8 call: one upload per picture (staged through libsadhip's page-locked planes),
 // the Go luminance -- color.GrayModel on alpha-premultiplied 16-bit channels, bit for bit -- and the disparity
 // search on the device, one download.  No gray plane exists on the host.
 func imagesHIP(lpix []uint8, lstride int, rpix []uint8, rstride int, w, h int, p Parameters) (*image.Gray, error) {

@@ -70,7 +70,7 @@ def test_product_library_reads_no_environment():
     und = subprocess.check_output(["nm", "-D", "--undefined-only", capi.LIB_PATH], text=True)
     assert "getenv" not in und
     blob = open(capi.LIB_PATH, "rb").read()
-    for name in (b"SADHIP_TUNE", b"SADHIP_PINNED_STAGING", b"SADHIP_BATCH_SEQ", b"NOPEN"):
+    for name in (b"SADHIP_TUNE", b"SADHIP_PINNED_STAGING", b"SADHIP_TUNE_HOSTCOPY", b"SADHIP_BATCH_SEQ", b"NOPEN"):
         assert name not in blob, name
 
 

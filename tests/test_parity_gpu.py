@@ -992,6 +992,61 @@ def test_pool_workers_are_pinned_next_to_their_device():
         assert all(np.array_equal(o, oracle.disparity_closed(L, R, 9, 32)) for o in outs)
 
 
+def test_pageable_memory_is_staged_in_bands_by_the_copy_threads(ctx):
+    """Caller memory the library did not page-lock itself never reaches a copy engine: the host
+    threads of the context copy it into / out of page-locked planes first -- rows split over the copy threads, frames
+    above 8 MB in bands.  Frames large enough for more than one band (17 MB planes, 33 MB decoded pictures), strided
+    views with odd base alignment on both sides, a guard page right behind the last input byte, region calls with a
+    column offset, and a small frame (one thread, one band): same bytes as the device-resident entry point, nothing
+    written outside the caller's rows."""
+    import torch
+    W, H, B, D = 8192, 2100, 5, 16
+    big_l, big_r = sha.synth.synth_pair(4242, W + 96, H + 3)
+    L, R = big_l[1:H + 1, 37:W + 37], big_r[2:H + 2, 11:W + 11]            # non-contiguous views, odd base alignment
+    Lc, Rc = np.ascontiguousarray(L), np.ascontiguousarray(R)
+    c = capi.Context(0, W, H, 1)
+    try:
+        dL, dR = torch.from_numpy(Lc)[None].cuda(), torch.from_numpy(Rc)[None].cuda()
+        dO = torch.empty_like(dL)
+        c.disparity_dev(dL, dR, dO, B, D)
+        torch.cuda.synchronize()
+        exp = dO[0].cpu().numpy()
+        for y0 in (0, 1047, H - 4):                                           # band seams and both ends against the oracle
+            assert np.array_equal(exp[y0:y0 + 4], oracle.disparity_rows_mt(Lc, Rc, B, D, y0, y0 + 4, 8))
+        out = np.full((H, W + 45), 0xAB, np.uint8)
+        c.disparity(L, R, B, D, out=out[:, 5:W + 5])
+        assert np.array_equal(out[:, 5:W + 5], exp)
+        assert (out[:, :5] == 0xAB).all() and (out[:, W + 5:] == 0xAB).all()
+        # the last byte of each input is the last byte before an inaccessible page
+        gl, ml = _guarded_copy(Lc)
+        gr, mr = _guarded_copy(Rc)
+        assert np.array_equal(c.disparity(gl, gr, B, D), exp)
+        # three frames in flight through the batch entry point, outputs in caller arrays
+        outs = [np.full((H, W), 0x11 * (i + 1), np.uint8) for i in range(4)]
+        c.disparity_batch([gl, Lc, Lc, gl], [gr, Rc, gr, Rc], B, D, outs=outs)
+        assert all(np.array_equal(o, exp) for o in outs)
+        wide = np.full((5, H, W + 45), 0xCD, np.uint8)                      # strided frames in, strided rows out
+        c.disparity_batch([L] * 5, [R] * 5, B, D, outs=[wide[i, :, 7:W + 7] for i in range(5)])
+        assert all(np.array_equal(wide[i, :, 7:W + 7], exp) for i in range(5))
+        assert (wide[:, :, :7] == 0xCD).all() and (wide[:, :, W + 7:] == 0xCD).all()
+        del gl, gr; ml.close(); mr.close()
+        # regions: a column offset inside the staged result rows, bands of the inputs only
+        for reg in ((4097, 1000, 8192, 2100), (3, 0, 8000, 64), (8191, 2099, 8192, 2100)):
+            assert np.array_equal(c.disparity_region(L, R, B, D, reg), exp[reg[1]:reg[3], reg[0]:reg[2]])
+    finally:
+        c.close()
+    # decoded pictures: 33 MB each at 4K, strided (a sub-picture of a larger one)
+    rng = np.random.default_rng(99)
+    pic = rng.integers(0, 256, (2, 2160 + 2, 3840 + 8, 4), dtype=np.uint8)
+    lp, rp = pic[0, 1:2161, 3:3843], pic[1, 2:2162, 5:3845]
+    gl_, gr_ = ctx.gray(lp), ctx.gray(rp)
+    assert np.array_equal(gl_, oracle.gray_from_nrgba(np.ascontiguousarray(lp)))
+    assert np.array_equal(ctx.disparity_rgba(lp, rp, 7, 32), ctx.disparity(gl_, gr_, 7, 32))
+    # a small frame: below the threshold of the copy threads
+    l, r = sha.synth.synth_pair(5, 200, 90)
+    assert np.array_equal(ctx.disparity(l, r, 9, 64), _expect(l, r, 9, 64))
+
+
 def test_device_resident_batch(ctx):
     import torch
     Ls, Rs = sha.synth.synth_batch_torch([1000, 1001, 1002], 300, 80, "cuda:0")

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Round 4: what staging pageable caller memory through the context's page-locked planes costs, and how many bands the
+staged copies should be cut into.  Diagnostics build only (SADHIP_LIB=.../libsadhip_tune.so; the context reads
+SADHIP_TUNE_HOSTCOPY / SADHIP_TUNE_BANDKB when it is created).  1920x1080, BlockSize 9, MaxDisparity 64 (BASELINE config 3):
+median of 30 synchronous sadhip_disparity_u8 calls on pageable numpy arrays, a 64-pair sadhip_disparity_batch_u8 on
+pageable arrays, sadhip_disparity_rgba_u8 and sadhip_gray_u8 on pageable RGBA pictures.  "direct" (rounds 2-4: the runtime
+locks the caller's pages) runs LAST and only with --direct.
+usage (GPU box): SADHIP_LIB=steroscopic-hardware_amd/lib/libsadhip_tune.so tools/ab_hostcopy.py [--direct]"""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO]
+import numpy as np
+import steroscopic_hardware_amd as sha
+from steroscopic_hardware_amd import capi
+if os.environ.get("SADHIP_LIB"): capi.LIB_PATH = os.path.abspath(os.environ["SADHIP_LIB"])
+W, H, B, D, NB = 1920, 1080, 9, 64, 64
+pairs = [sha.synth.synth_pair(100 + i, W, H) for i in range(NB)]
+ls, rs = [p[0] for p in pairs], [p[1] for p in pairs]
+os_ = [np.zeros((H, W), np.uint8) for _ in range(NB)]
+rgba = np.random.default_rng(5).integers(0, 256, (2, H, W, 4), dtype=np.uint8)
+ref = None
+
+def med(fn, n=30):
+    for _ in range(3): fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return sorted(ts)[n // 2] * 1e3, min(ts) * 1e3
+
+modes = [("default", 0, 0)] + [("staged", 8192, t) for t in (1, 2, 4, 6, 8)] + [("staged", kb, 6) for kb in (2048, 1024, 512)] + ([("direct", 0, 1)] if "--direct" in sys.argv else [])
+for mode, bands, threads in modes:
+    if mode == "default":                                    # what the product library does: no knob set
+        for k in ("SADHIP_TUNE_HOSTCOPY", "SADHIP_TUNE_BANDKB", "SADHIP_TUNE_COPYTHREADS"): os.environ.pop(k, None)
+    else:
+        os.environ["SADHIP_TUNE_HOSTCOPY"] = mode
+        os.environ["SADHIP_TUNE_BANDKB"] = str(max(bands, 4))
+        os.environ["SADHIP_TUNE_COPYTHREADS"] = str(threads)
+    ctx = capi.Context(0, W, H, 1)
+    o = np.zeros((H, W), np.uint8)
+    m1, lo1 = med(lambda: ctx.disparity(ls[0], rs[0], B, D, out=o))
+    k, t = ctx.last_timing()
+    it = iter(range(10 ** 9))
+    def cold():                                               # a different pair and output every call: nothing in the caches
+        i = next(it) % NB
+        ctx.disparity(ls[i], rs[i], B, D, out=os_[i])
+    mc, loc = med(cold, 48)
+    if ref is None: ref = o.copy()
+    ok = bool(np.array_equal(o, ref))
+    ctx.disparity_batch(ls, rs, B, D, outs=os_)
+    t0 = time.perf_counter(); ctx.disparity_batch(ls, rs, B, D, outs=os_); dt = time.perf_counter() - t0
+    ok = ok and bool(np.array_equal(os_[0], ref))
+    m2, lo2 = med(lambda: ctx.disparity_rgba(rgba[0], rgba[1], B, D), 20)
+    m3, lo3 = med(lambda: ctx.gray(rgba[0]), 20)
+    print(f"{mode:7s} band={bands} KiB threads={threads}: single call {m1:.3f} ms (min {lo1:.3f}, kernel {k:.3f}); over 64 different pairs {mc:.3f} ms (min {loc:.3f})  batch {NB / dt:7.0f} pairs/s  "
+          f"rgba call {m2:.3f} ms (min {lo2:.3f})  gray call {m3:.3f} ms (min {lo3:.3f})  same result={ok}", flush=True)
+    ctx.close()
