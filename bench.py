@@ -179,6 +179,15 @@ def _time_reference_c(ctx, sha):
         return {"error": repr(e)}
 
 
+def _to_host(t):
+    """Device tensor -> numpy through torch's page-locked allocator (never a device copy into pageable memory: DESIGN.md 6b)."""
+    import torch
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    torch.cuda.synchronize(t.device)
+    return p.numpy().copy()
+
+
 def _host_legs(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf):
     """SURVEY 8(d) "separately: end-to-end incl. H2D + D2H" and 8(e) "(ii) host-fed": the same frames from HOST
     memory through the entry points a Go / C++ host calls (examples/run.stream.go:46-62 prints the same per-frame
@@ -186,7 +195,7 @@ def _host_legs(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf):
     import numpy as np
     capi = sha.capi
     frame = W * H
-    ref = out[:nf].cpu().numpy()                                  # the device-resident results of the timed launches
+    ref = _to_host(out[:nf])                                  # the device-resident results of the timed launches
     legs = {}
     # the thread that allocates (first-touches) the page-locked frames and makes the calls runs on the CPUs next to the
     # device (sadhip_device_describe): on a two-socket box whose GPU hangs on the other node every copy would cross the
@@ -217,7 +226,7 @@ def _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, r
     legs = {}
     with capi.HostBuffer(3 * nf * frame) as hb:
         blk = hb.view((3, nf, H, W))
-        blk[0] = Ls[:nf].cpu().numpy(); blk[1] = Rs[:nf].cpu().numpy()
+        blk[0] = _to_host(Ls[:nf]); blk[1] = _to_host(Rs[:nf])
         lefts, rights, outs = [blk[0, i] for i in range(nf)], [blk[1, i] for i in range(nf)], [blk[2, i] for i in range(nf)]
 
         def timed(fn, reps=3):
@@ -552,11 +561,11 @@ def main():
         def cpu_run(npairs, nthr):
             wall, ok = 0.0, True
             for i in range(npairs):
-                L0, R0 = Ls[i].cpu().numpy(), Rs[i].cpu().numpy()
+                L0, R0 = _to_host(Ls[i]), _to_host(Rs[i])
                 t1 = time.perf_counter()
                 cpu = oracle.disparity_rows_mt(L0, R0, block, maxdisp, 0, H, nthr)  # one full pair
                 wall += time.perf_counter() - t1
-                ok = ok and bool(np.array_equal(cpu, out[i].cpu().numpy()))
+                ok = ok and bool(np.array_equal(cpu, _to_host(out[i])))
             return wall, ok
 
         n1 = 1 if F >= 1 else 0                                   # one full pair single-threaded (~5-12 s)

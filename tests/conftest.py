@@ -124,3 +124,25 @@ def _real_pairs():
 
 REAL_PAIRS = _real_pairs()          # every picture pair the reference holds in testdata/, with the pinned digests
 REAL_CASES = [(k, bd) for k in sorted(REAL_PAIRS) for bd in sorted(REAL_PAIRS[k]["maps"], key=lambda s: tuple(map(int, s.split("/"))))]
+
+
+# ---- host <-> device copies of the GPU tests --------------------------------------------------------------------------
+# Through torch's page-locked allocator, never from / to pageable numpy memory: round 4 saw a process end with "Memory
+# access fault by GPU ... on address <a host heap page>" while the HIP runtime was copying from pageable arrays it had
+# locked in place.  The library no longer does that; the tests' own copies do not either.
+def to_device(a):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    d = p.cuda()
+    torch.cuda.synchronize()
+    return d
+
+
+def to_host(t):
+    import torch
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    torch.cuda.synchronize()
+    return p.numpy().copy()

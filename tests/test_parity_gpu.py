@@ -12,7 +12,7 @@ import pytest
 import oracle
 import steroscopic_hardware_amd as sha
 from steroscopic_hardware_amd import capi
-from conftest import REAL_CASES, REAL_PAIRS, load_real_gray, load_real_pixels
+from conftest import REAL_CASES, REAL_PAIRS, load_real_gray, load_real_pixels, to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -100,12 +100,12 @@ def test_real_inputs_complete_frames(ctx, name, key):
     mid = [sha.synth.synth_pair(4000 + i, w, h) for i in range(3)]
     Lb = np.stack([L] + [mid[i % 3][0] for i in range(n - 2)] + [L])
     Rb = np.stack([R] + [mid[i % 3][1] for i in range(n - 2)] + [R])
-    Ls, Rs = torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda()
+    Ls, Rs = to_device(Lb), to_device(Rb)
     out = torch.full_like(Ls, 0xCD)
     ctx.disparity_dev(Ls, Rs, out, b, d)
     torch.cuda.synchronize()
     assert capi.last_kernel_kind() == capi.KIND_COLWAVE
-    o = out.cpu().numpy()
+    o = to_host(out)
     assert np.array_equal(o[0], exp) and np.array_equal(o[n - 1], exp), (name, key, "batched layout")
     if w == 640:
         assert np.array_equal(o[1], _expect(mid[0][0], mid[0][1], b, d))
@@ -378,7 +378,7 @@ def test_generic_path_is_bounded_running_sum_kernel(ctx):
     assert capi.last_kernel_kind() == capi.KIND_GENERIC_SLIDING
     for i in range(3):
         Li, Ri = sha.synth.synth_pair(70 + i, 600, 80)
-        assert np.array_equal(out[i].cpu().numpy(), oracle.disparity_closed(Li, Ri, 41, 64))
+        assert np.array_equal(to_host(out[i]), oracle.disparity_closed(Li, Ri, 41, 64))
     # (3) the full-size case with a wall-time bound
     L, R = sha.synth.synth_pair(63, 1920, 1080)
     ctx.disparity(L, R, 63, 64)                                                   # warm-up (module load, scratch)
@@ -485,14 +485,14 @@ def test_u16_ring_chunks_of_four_and_mixed_chunk_plans(ctx):
             R[1] = np.roll(L[1], -min(D, 29), axis=1)
             L[2] = 255; R[2] = 0; R[2][:, w // 3:] = 255; R[2][:, 2 * w // 3:] = 0
             L[3] = 91; R[3] = 91
-            Ls, Rs = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+            Ls, Rs = to_device(L), to_device(R)
             a, b = torch.full_like(Ls, 0xCD), torch.full_like(Ls, 0xEE)
             ctx.disparity_dev(Ls, Rs, a, block, D, capi.FLAG_RAW)
             assert capi.last_kernel_kind() == capi.KIND_COLWAVE
             ctx.disparity_dev(Ls, Rs, b, block, D, capi.FLAG_RAW | capi.FLAG_FORCE_GENERIC)
             torch.cuda.synchronize()
-            got = a.cpu().numpy()
-            assert np.array_equal(got, b.cpu().numpy()), (block, w, D)
+            got = to_host(a)
+            assert np.array_equal(got, to_host(b)), (block, w, D)
             for i in range(4):                                   # two rows of every frame against the oracle, through the host path
                 one = ctx.disparity_region(L[i], R[i], block, D, (0, hh + 3, w, hh + 5), capi.FLAG_RAW)
                 assert np.array_equal(one, got[i][hh + 3:hh + 5]), (block, w, D, i)
@@ -528,14 +528,14 @@ def test_unpacked_kernels_any_max_disparity(ctx):
         R[1] = np.roll(L[1], -min(D - 3, w // 2), axis=1)               # a true shift deep in the range (the later passes win)
         L[2] = 255; R[2] = 0; R[2][:, w // 3:] = 255
         big = capi.Context(0, w, hgt, 1) if w > 3840 else ctx
-        Ls, Rs = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+        Ls, Rs = to_device(L), to_device(R)
         a, b = torch.full_like(Ls, 0xCD), torch.full_like(Ls, 0xEE)
         big.disparity_dev(Ls, Rs, a, block, D)
         assert capi.last_kernel_kind() == capi.KIND_COLWAVE
         big.disparity_dev(Ls, Rs, b, block, D, capi.FLAG_FORCE_GENERIC)
         torch.cuda.synchronize()
-        got = a.cpu().numpy()
-        assert np.array_equal(got, b.cpu().numpy()), (block, w, D)
+        got = to_host(a)
+        assert np.array_equal(got, to_host(b)), (block, w, D)
         for i in range(3):
             reg = (0, hh + 1, w, hh + 3)
             assert np.array_equal(got[i][hh + 1:hh + 3], oracle.disparity_rows_mt(L[i], R[i], block, D, hh + 1, hh + 3, min(16, os.cpu_count() or 1))), (block, w, D, i)
@@ -567,14 +567,14 @@ def test_packed_mixed_chunk_plans(ctx):
                 R[1] = np.roll(L[1], -min(D, 37), axis=1)
                 L[2] = 255; R[2] = 0; R[2][:, w // 3:] = 255; R[2][:, 2 * w // 3:] = 0
                 L[3] = 91; R[3] = 91
-                Ls, Rs = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+                Ls, Rs = to_device(L), to_device(R)
                 a, b = torch.full_like(Ls, 0xCD), torch.full_like(Ls, 0xEE)
                 ctx.disparity_dev(Ls, Rs, a, block, D, capi.FLAG_RAW)
                 assert capi.last_kernel_kind() == capi.KIND_COLWAVE
                 ctx.disparity_dev(Ls, Rs, b, block, D, capi.FLAG_RAW | capi.FLAG_FORCE_GENERIC)
                 torch.cuda.synchronize()
-                got = a.cpu().numpy()
-                assert np.array_equal(got, b.cpu().numpy()), (block, w, D)
+                got = to_host(a)
+                assert np.array_equal(got, to_host(b)), (block, w, D)
                 for i in range(4):
                     reg = (0, hh + 3, w, hh + 5)
                     assert np.array_equal(got[i][hh + 3:hh + 5], oracle.disparity_closed(L[i], R[i], block, D, region=reg, raw=True)), (block, w, D, i)
@@ -1006,11 +1006,11 @@ def test_pageable_memory_is_staged_in_bands_by_the_copy_threads(ctx):
     Lc, Rc = np.ascontiguousarray(L), np.ascontiguousarray(R)
     c = capi.Context(0, W, H, 1)
     try:
-        dL, dR = torch.from_numpy(Lc)[None].cuda(), torch.from_numpy(Rc)[None].cuda()
+        dL, dR = to_device(Lc[None]), to_device(Rc[None])
         dO = torch.empty_like(dL)
         c.disparity_dev(dL, dR, dO, B, D)
         torch.cuda.synchronize()
-        exp = dO[0].cpu().numpy()
+        exp = to_host(dO[0])
         for y0 in (0, 1047, H - 4):                                           # band seams and both ends against the oracle
             assert np.array_equal(exp[y0:y0 + 4], oracle.disparity_rows_mt(Lc, Rc, B, D, y0, y0 + 4, 8))
         out = np.full((H, W + 45), 0xAB, np.uint8)
@@ -1055,8 +1055,8 @@ def test_device_resident_batch(ctx):
     torch.cuda.synchronize()
     for i in range(3):
         L, R = sha.synth.synth_pair(1000 + i, 300, 80)
-        assert np.array_equal(Ls[i].cpu().numpy(), L) and np.array_equal(Rs[i].cpu().numpy(), R)
-        assert np.array_equal(out[i].cpu().numpy(), _expect(L, R, 9, 64))
+        assert np.array_equal(to_host(Ls[i]), L) and np.array_equal(to_host(Rs[i]), R)
+        assert np.array_equal(to_host(out[i]), _expect(L, R, 9, 64))
 
 
 _TR_SHAPES = {
@@ -1092,7 +1092,7 @@ def test_batches_triple_column_form(ctx, block):
         Lb[3] = 77; Rb[3] = 77                                   # flat: every candidate ties
         Rb[4] = Lb[4]                                            # identical: SAD 0 at d = 0
         Lb[5] = 255; Rb[5] = 0                                   # every window at the maximum: ties at the largest keys
-        Ls, Rs = torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda()
+        Ls, Rs = to_device(Lb), to_device(Rb)
         out = torch.full_like(Ls, 0xCD)
         ref = torch.full_like(Ls, 0xEE)
         raw = capi.FLAG_RAW if D <= 255 else 0
@@ -1100,7 +1100,7 @@ def test_batches_triple_column_form(ctx, block):
         assert capi.last_kernel_kind() == capi.KIND_COLWAVE
         ctx.disparity_dev(Ls, Rs, ref, block, D, raw | capi.FLAG_FORCE_GENERIC)
         torch.cuda.synchronize()
-        got, exp = out.cpu().numpy(), ref.cpu().numpy()
+        got, exp = to_host(out), to_host(ref)
         assert np.array_equal(got, exp), (block, w, h, D, np.argwhere(got != exp)[:4])
         for i in (0, 1, 2, n - 1):                               # and against the oracle itself
             assert np.array_equal(got[i], _expect(Lb[i], Rb[i], block, D, raw=bool(raw))), (block, w, D, i)
@@ -1126,8 +1126,8 @@ def test_multi_pass_batch_beyond_one_grid(ctx):
     torch.cuda.synchronize()
     assert capi.last_kernel_kind() == capi.KIND_COLWAVE
     for i in (0, 1, 32767, 32768, 32769, n - 1):
-        L, R = Ls[i].cpu().numpy(), Rs[i].cpu().numpy()
-        assert np.array_equal(out[i].cpu().numpy(), _expect(L, R, block, D)), i
+        L, R = to_host(Ls[i]), to_host(Rs[i])
+        assert np.array_equal(to_host(out[i]), _expect(L, R, block, D)), i
     # every frame against the generic kernel (independent second implementation), on the device
     gen = torch.empty_like(Ls)
     ctx.disparity_dev(Ls, Rs, gen, block, D, capi.FLAG_FORCE_GENERIC)
@@ -1295,10 +1295,10 @@ def test_batched_layout_complete_frames_vs_literal_oracle(ctx):
     rows, passes = _seam_rows(W, H, B, D, n=n)
     thr = min(16, os.cpu_count() or 1)
     for i in (0, 61, n - 1):                                       # complete frames
-        L, R = Ls[i].cpu().numpy(), Rs[i].cpu().numpy()
-        assert np.array_equal(out[i].cpu().numpy(), oracle.disparity_rows_mt(L, R, B, D, 0, H, thr)), (i, passes)
+        L, R = to_host(Ls[i]), to_host(Rs[i])
+        assert np.array_equal(to_host(out[i]), oracle.disparity_rows_mt(L, R, B, D, 0, H, thr)), (i, passes)
     for i in range(1, n - 1, 9):                                   # the others: around every seam of this launch
-        L, R, o = Ls[i].cpu().numpy(), Rs[i].cpu().numpy(), out[i].cpu().numpy()
+        L, R, o = to_host(Ls[i]), to_host(Rs[i]), to_host(out[i])
         for ya, yb in rows[:6]:
             assert np.array_equal(o[ya:yb], oracle.disparity_rows_mt(L, R, B, D, ya, yb, thr)), (i, ya, yb, passes)
 
@@ -1312,7 +1312,7 @@ def test_config4_stream_shard(ctx):
     out = torch.empty_like(Ls)
     ctx.disparity_dev(Ls, Rs, out, 9, 64)
     torch.cuda.synchronize()
-    o = out.cpu().numpy()
+    o = to_host(out)
     d1 = hashlib.sha256(b"".join(hashlib.sha256(o[i].tobytes()).digest() for i in range(len(seeds)))).hexdigest()
     for i, sd in enumerate(seeds):
         L, R = sha.synth.synth_pair(sd, 1920, 1080)
@@ -1321,6 +1321,6 @@ def test_config4_stream_shard(ctx):
     out.zero_()
     ctx.disparity_dev(Ls, Rs, out, 9, 64)
     torch.cuda.synchronize()
-    o2 = out.cpu().numpy()
+    o2 = to_host(out)
     d2 = hashlib.sha256(b"".join(hashlib.sha256(o2[i].tobytes()).digest() for i in range(len(seeds)))).hexdigest()
     assert d1 == d2
