@@ -5,6 +5,8 @@ import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "oracle")]
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _pinned import to_host
 import steroscopic_hardware_amd as sha, oracle
 if os.environ.get("SADHIP_LIB"): sha.capi.LIB_PATH = os.path.abspath(os.environ["SADHIP_LIB"])   # other builds
 elif any(k.startswith("SADHIP_TUNE_") for k in os.environ):      # the knobs exist only in the diagnostics build (make -C csrc tune)
@@ -22,9 +24,9 @@ e0.record(); K = 5
 for _ in range(K): ctx.disparity_dev(Ls, Rs, out, B, D)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / K / N
-L0, R0 = Ls[0].cpu().numpy(), Rs[0].cpu().numpy()
+L0, R0 = to_host(Ls[0]), to_host(Rs[0])
 y0 = H // 2
-ok = np.array_equal(out[0, y0:y0 + 4].cpu().numpy(), oracle.disparity_closed(L0, R0, B, D, region=(0, y0, W, y0 + 4)))
-ok2 = np.array_equal(out[0, :3].cpu().numpy(), oracle.disparity_closed(L0, R0, B, D, region=(0, 0, W, 3)))
+ok = np.array_equal(to_host(out[0, y0:y0 + 4]), oracle.disparity_closed(L0, R0, B, D, region=(0, y0, W, y0 + 4)))
+ok2 = np.array_equal(to_host(out[0, :3]), oracle.disparity_closed(L0, R0, B, D, region=(0, 0, W, 3)))
 c = sha.synth.candidates_per_pair(W, H, B, D)
 print(f"{W}x{H} b{B} D{D} n={N} kind={sha.capi.kernel_kind(W,H,B,D)}: {ms*1e3:.1f} us/frame  {c/ms/1e6:.0f} Gcand/s  {3*W*H/ms/1e6:.1f} GB/s  parity={ok and ok2}")

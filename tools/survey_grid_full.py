@@ -12,6 +12,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "oracle")]
 import numpy as np
 import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _pinned import to_device, to_host
 import oracle
 import steroscopic_hardware_amd as sha
 from steroscopic_hardware_amd import capi
@@ -27,11 +29,11 @@ Ls, Rs = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]); del
 if REAL:
     from PIL import Image
     g = os.path.join(REPO, "tests", "golden")
-    Ls[0] = torch.from_numpy(oracle.gray_from_rgb8(np.array(Image.open(os.path.join(g, "im0.png"))))).to(dev)
-    Rs[0] = torch.from_numpy(oracle.gray_from_rgb8(np.array(Image.open(os.path.join(g, "im1.png"))))).to(dev)
+    Ls[0] = to_device(oracle.gray_from_rgb8(np.array(Image.open(os.path.join(g, "im0.png")))), dev)
+    Rs[0] = to_device(oracle.gray_from_rgb8(np.array(Image.open(os.path.join(g, "im1.png")))), dev)
 out = torch.empty_like(Ls)
 ctx = capi.Context(0, W, H, 1)
-L0, R0 = Ls[0].cpu().numpy(), Rs[0].cpu().numpy()
+L0, R0 = to_host(Ls[0]), to_host(Rs[0])
 BANDS = (0, 137, 402, H // 2 - 1, 803, H - 3) if REAL else (0, H // 2 - 1)
 thr = min(16, os.cpu_count() or 1)
 blocks = [3, 5, 7, 9, 11, 13, 15, 16, 17, 19, 21, 23, 25, 27, 29, 31]
@@ -51,7 +53,7 @@ with open(out_path, "w") as f:
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 5 / N * 1e3
             kind = capi.last_kernel_kind()
-            o0 = out[0].cpu().numpy()
+            o0 = to_host(out[0])
             ok = True
             for y0 in BANDS:
                 ok = ok and np.array_equal(o0[y0:y0 + 3], oracle.disparity_rows_mt(L0, R0, b, d, y0, y0 + 3, thr))
