@@ -114,8 +114,9 @@ SADHIP_API const char* sadhip_last_error(void);                  /* thread-local
 
 /* ---- context ------------------------------------------------------------------------------
  * Replaces the worker pool of SetupConcurrentSAD (pkg/despair/sad.go:29-113): one context owns
- * the device planes (three frame slots, each with page-locked host planes of the same size for
- * caller memory that is not page-locked), scratch and HIP streams for frames up to max_w x max_h.
+ * the device planes (three frame slots; each gets page-locked host planes of the same size when the
+ * first frame in memory that is not page-locked arrives), scratch and HIP streams for frames up to
+ * max_w x max_h.
  * max_batch (>= 1) is a sizing hint kept for ABI stability: batches of ANY length stream through
  * the slots.  Created when the Go shim's pipeline is set up, destroyed when its input channel
  * is closed (sad.go:106-110, pkg/camera/output.go:213-220). */

@@ -495,9 +495,6 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
     if (e == hipSuccess) e = hipEventCreate(&s.k0);
     if (e == hipSuccess) e = hipEventCreate(&s.k1);
     for (auto& b : s.band) if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hL, c->plane, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hR, c->plane, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s.hO, c->plane, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dL, c->plane);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dR, c->plane);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dO, c->plane);
@@ -606,6 +603,21 @@ static inline int band_count(int rows, size_t pitch, size_t band_bytes)
 }
 static inline int band_row(int r0, int r1, int nb, int b) { return r0 + (int)((long long)(r1 - r0) * b / nb); }
 
+// the slot's page-locked host planes: allocated when the first frame that needs staging arrives (a context that only ever
+// sees device-resident or page-locked frames never locks host memory of its own)
+static int ensure_stage(sadhip_ctx* c, Slot& s)
+{
+  for (uint8_t** p : {&s.hL, &s.hR, &s.hO})
+    if (!*p) {
+      const hipError_t e = hipHostMalloc((void**)p, c->plane, hipHostMallocDefault);
+      if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(e == hipErrorOutOfMemory ? SADHIP_ERR_NOMEM : SADHIP_ERR_HIP, "page-locked staging plane (%zu B): %s", c->plane, hipGetErrorString(e));
+      }
+    }
+  return SADHIP_OK;
+}
+
 static inline void copy_rows(sadhip_ctx* c, const RowCopy& rc, int rows)
 {
   if (c->gang) c->gang->rows(rc, 0, rows); else copy_part(rc, 0, rows);
@@ -667,6 +679,7 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
     if (rband1 > band0)
       HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, rw, rband1 - band0, hipMemcpyHostToDevice, s.stream));
   } else {
+    if (int st = ensure_stage(c, s)) return st;
     if (int st = upload_staged(c, s.stream, s.dL, s.hL, pitch, left, (size_t)lstride, (size_t)w, band0, band1)) return st;
     if (int st = upload_staged(c, s.stream, s.dR, s.hR, pitch, right, (size_t)rstride, (size_t)rw, band0, rband1)) return st;
   }
@@ -695,6 +708,7 @@ static int enqueue_download(sadhip_ctx* c, Slot& s, int w, int x0, int x1, int r
     HIPTRY(hipMemcpy2DAsync(s.out, s.ostride, s.dO + x0, pitch, x1 - x0, rows, hipMemcpyDeviceToHost, s.stream));
     return SADHIP_OK;
   }
+  if (int st = ensure_stage(c, s)) return st;
   s.out_bands = band_count(rows, pitch, c->band_bytes);
   for (int b = 0; b < s.out_bands; ++b) {
     const int a0 = band_row(0, rows, s.out_bands, b), a1 = band_row(0, rows, s.out_bands, b + 1);

@@ -35,3 +35,9 @@ def test_stress_boundary_left_right_sizes_and_page_locked_layouts():
     page-locked batch layouts (column windows of wider images, scattered order, tight / windowed outputs with sentinel
     bytes) against the pageable path."""
     assert _tool("stress_boundary").run(240, 406) == (0, 0)
+
+
+def test_stress_staged_host_copies_random_sizes_strides_regions():
+    """Random frame sizes around the thresholds of the staged host path (copy threads from 512 KB, bands above 8 MB), row
+    strides, base alignments, guard pages, regions, batches, decoded pictures: against the device-resident entry point."""
+    assert _tool("stress_hostcopy").run(36, 407) == 0
