@@ -1,0 +1,124 @@
+// copy_gang.h -- the host threads that move caller memory into / out of a context's page-locked planes (sadhip.hip).
+// Plain C++17, no HIP: tests/test_copy_gang_cpu.py builds it alone under ThreadSanitizer and AddressSanitizer.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+// The host threads that move caller memory into / out of the context's page-locked planes.
+// One core copies frames that are not in its caches at 10-20 GB/s (tools/ab_hostcopy.py: 0.3-0.5 ms for
+// the 6 MB of a 1080p pair), a fraction of what the bus then moves; the helpers split the rows with the
+// calling thread.  The helpers touch host memory only -- no HIP call is made on them --
+// are started on the first large copy of a context and inherit the affinity of the thread that
+// starts them (a pool worker is pinned to the device's CPUs).
+namespace sadhip {
+
+
+struct RowCopy {
+  uint8_t* dst; size_t dpitch; const uint8_t* src; size_t spitch; size_t wbytes;
+  bool whole_rows;           // the bytes between the rows may be copied too (dst is a plane of ours, src readable to its last row's wbytes)
+};
+
+inline void copy_part(const RowCopy& c, int r0, int r1)
+{
+  if (r1 <= r0) return;
+  if (c.dpitch == c.spitch && (c.wbytes == c.dpitch || c.whole_rows)) {
+    memcpy(c.dst + (size_t)r0 * c.dpitch, c.src + (size_t)r0 * c.spitch, (size_t)(r1 - r0 - 1) * c.dpitch + c.wbytes);
+    return;
+  }
+  for (int r = r0; r < r1; ++r) memcpy(c.dst + (size_t)r * c.dpitch, c.src + (size_t)r * c.spitch, c.wbytes);
+}
+
+class CopyGang {
+ public:
+  static constexpr size_t kMinBytes = (size_t)512 << 10;      // below this the calling thread copies alone
+  static constexpr int kSpinUs = 150;   // a helper polls this long for the next piece before it sleeps (L, R and the result of a
+                                        // call follow each other within that; waking a sleeping core costs 20-50 us per piece)
+  explicit CopyGang(int helpers) : helpers_(helpers) {}
+  ~CopyGang()
+  {
+    { std::lock_guard<std::mutex> lk(mu_); stop_.store(true, std::memory_order_release); }
+    cv_work_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void rows(const RowCopy& c, int r0, int r1)
+  {
+    const int n = r1 - r0;
+    if (helpers_ <= 0 || n < 2 * (helpers_ + 1) || (size_t)n * c.wbytes < kMinBytes || !start()) { copy_part(c, r0, r1); return; }
+    const int parts = helpers_ + 1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);                     // (the increment under the lock: no helper misses its wake-up)
+      job_ = c; j0_ = r0; j1_ = r1;
+      pending_.store(helpers_, std::memory_order_relaxed);
+      gen_.fetch_add(1, std::memory_order_release);
+    }
+    cv_work_.notify_all();
+    copy_part(c, r0 + (int)((long long)n * helpers_ / parts), r1);          // the caller's own share: the last one
+    if (!spin_until([&] { return pending_.load(std::memory_order_acquire) == 0; })) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+    }
+  }
+
+ private:
+  template <class F> static bool spin_until(F&& done)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0;; ++i) {
+      if (done()) return true;
+      __builtin_ia32_pause();
+      if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) return false;
+    }
+  }
+  bool start()
+  {
+    if (!th_.empty()) return true;
+    if (failed_) return false;
+    try {
+      for (int k = 0; k < helpers_; ++k) th_.emplace_back([this, k] { work(k); });
+    } catch (...) {                                            // no threads to be had: the caller copies alone
+      { std::lock_guard<std::mutex> lk(mu_); stop_.store(true, std::memory_order_release); }
+      cv_work_.notify_all();
+      for (auto& t : th_) t.join();
+      th_.clear(); stop_.store(false, std::memory_order_release); failed_ = true;
+      return false;
+    }
+    return true;
+  }
+  void work(int k)
+  {
+    unsigned seen = 0;
+    for (;;) {
+      auto news = [&] { return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen; };
+      if (!spin_until(news)) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_work_.wait(lk, news);
+      }
+      if (stop_.load(std::memory_order_acquire)) return;
+      seen = gen_.load(std::memory_order_acquire);
+      const RowCopy c = job_; const int r0 = j0_, r1 = j1_;   // stable until every helper has reported (rows() waits for that)
+      const int n = r1 - r0, parts = helpers_ + 1;
+      copy_part(c, r0 + (int)((long long)n * k / parts), r0 + (int)((long long)n * (k + 1) / parts));
+      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        { std::lock_guard<std::mutex> lk(mu_); }              // the caller is either polling or inside wait(): never in between
+        cv_done_.notify_one();
+      }
+    }
+  }
+  const int helpers_;
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  RowCopy job_{}; int j0_ = 0, j1_ = 0;
+  std::atomic<unsigned> gen_{0};
+  std::atomic<int> pending_{0};
+  std::atomic<bool> stop_{false};
+  bool failed_ = false;
+};
+
+}  // namespace sadhip
