@@ -516,6 +516,7 @@ static inline void copy_rows(sadhip_ctx* c, const RowCopy& rc, int rows)
 static int upload_staged(sadhip_ctx* c, hipStream_t st, uint8_t* dev, uint8_t* stage, size_t pitch,
                          const uint8_t* src, size_t stride, size_t wbytes, int r0, int r1)
 {
+  if (r1 <= r0) return SADHIP_OK;                           // (a right picture that ends above the band: nothing of it exists here)
   const int nb = band_count(r1 - r0, pitch, c->band_bytes);
   for (int b = 0; b < nb; ++b) {
     const int a0 = band_row(r0, r1, nb, b), a1 = band_row(r0, r1, nb, b + 1);
