@@ -10,7 +10,7 @@ here="$(cd "$(dirname "$0")" && pwd)"; ub="$here/ubench"
 out="${1:-gpurun_out/ubench}"; mkdir -p "$out"
 HIPCC=/opt/rocm/bin/hipcc
 rc=0
-for name in ${UBENCH_ONLY:-valu_rates valu_rates2 valu_mix valu_runs block_bench pcie_bw dpp_sub hbm_calib simd_map bank_test malloc_async buffer_range h2d_paths pin_reuse}; do
+for name in ${UBENCH_ONLY:-valu_rates valu_rates2 valu_mix valu_runs block_bench pcie_bw dpp_sub hbm_calib simd_map bank_test malloc_async buffer_range h2d_paths pin_reuse dpp_hazard}; do
   src="$ub/$name.hip"; bin="$ub/$name"
   if [ ! -x "$bin" ] || [ "$src" -nt "$bin" ]; then
     $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-command-line-argument -Wno-unused-result -o "$bin" "$src" 2> "$out/build_$name.log" || { echo "build of $name failed"; rc=1; continue; }
