@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Summary of tools/trace_hostfed.sh's kernel + memory-copy trace of the host-fed entry points (tools/bench_hostfed.py:
+1 + 8 synchronous single calls, a warm-up batch and a timed batch of 32 pairs, all from pageable numpy memory = the staged
+path): what the copy engines and the kernel queue were doing, and how much of it overlapped.
+usage: summarize_hostfed.py <prof dir> <out.md>"""
+import csv, glob, os, sys
+
+d, out = sys.argv[1], sys.argv[2]
+def rows(pat):
+    f = glob.glob(os.path.join(d, pat))[0]
+    return list(csv.DictReader(open(f)))
+cp = [(r["Direction"].rsplit("_", 3)[-3][0] + "2" + r["Direction"][-6], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows("*memory_copy_trace.csv")]
+cp = [("H2D" if "HOST_TO_DEVICE" in r["Direction"] else "D2H", int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows("*memory_copy_trace.csv")]
+kr = [("K", int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows("*kernel_trace.csv") if "k_colwave" in r["Kernel_Name"] or "k_disparity" in r["Kernel_Name"]]
+ev = sorted(cp + kr, key=lambda e: e[1])
+W, H, PITCH = 1920, 1080, 2048
+plane = PITCH * H
+
+def union(iv):
+    iv = sorted(iv); tot = 0; cs, ce = None, None
+    for s, e in iv:
+        if cs is None or s > ce:
+            if cs is not None: tot += ce - cs
+            cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    return tot + (ce - cs if cs is not None else 0)
+
+def phase(events, title, npairs):
+    t0, t1 = min(e[1] for e in events), max(e[2] for e in events)
+    wall = t1 - t0
+    lines = [f"### {title}", "", f"{npairs} pairs, {wall / 1e3:.1f} us from the first upload's start to the last download's end = {wall / npairs / 1e3:.1f} us per pair on the device's clock", "",
+             "| activity | events | mean us | busy us (union) | share of the span |", "|---|---|---|---|---|"]
+    busy = {}
+    for k, name in (("H2D", "uploads (one 2.2 MB plane each)"), ("K", "disparity kernel"), ("D2H", "downloads (one 2.2 MB plane each)")):
+        iv = [(s, e) for kk, s, e in events if kk == k]
+        busy[k] = union(iv)
+        mean = sum(e - s for s, e in iv) / max(len(iv), 1)
+        lines.append(f"| {name} | {len(iv)} | {mean / 1e3:.1f} | {busy[k] / 1e3:.1f} | {busy[k] / wall:.2f} |")
+    allb = union([(s, e) for _, s, e in events])
+    lines += [f"| anything | {len(events)} | | {allb / 1e3:.1f} | {allb / wall:.2f} |", "",
+              f"sum of the three busy times / span = {sum(busy.values()) / wall:.2f} (1.00 = no overlap at all; 3.00 = all three busy all the time); idle {1 - allb / wall:.2f} of the span",
+              f"upload rate while an upload is running: {plane / (sum(e - s for k, s, e in events if k == 'H2D') / max(1, sum(1 for k, _, _ in events if k == 'H2D'))) :.1f} GB/s per copy; download {plane / (sum(e - s for k, s, e in events if k == 'D2H') / max(1, sum(1 for k, _, _ in events if k == 'D2H'))):.1f} GB/s", ""]
+    return lines
+
+nk = len(kr)
+assert nk >= 32 + 32 + 9, nk
+# the last 32 kernels and the copies around them = the timed batch; the first 9 kernels = the single calls
+kb = kr[-32:]
+tb0 = min(s for _, s, _ in kb)
+cpb = [e for e in cp if e[2] >= tb0 - 400_000 and e[1] >= kr[-33][2] - 50_000]   # copies after the warm-up batch's last kernel
+cpb = sorted(cpb, key=lambda e: e[1])[-96:]
+batch = sorted(kb + cpb, key=lambda e: e[1])
+ks = kr[1:9]
+ts0, ts1 = ks[0][1], ks[-1][2]
+single = sorted(ks + [e for e in cp if e[2] > kr[0][2] and e[1] < kr[9][1] - 100_000][:24], key=lambda e: e[1])
+md = ["# Host-fed entry points under `rocprofv3 --kernel-trace --memory-copy-trace` (no counters)", "",
+      "`tools/trace_hostfed.sh` -> `tools/bench_hostfed.py`: 1920x1080, BlockSize 9, MaxDisparity 64, frames in pageable numpy memory -- the staged path: the context's copy threads fill / empty page-locked planes, the copy engines only ever see those.", "",
+      f"Trace totals: {len(cp)} copies, {nk} disparity kernels.", "",
+      "**Read the spans with care**: the copy tracer completes every copy before the next one starts on this stack (the traced batch runs at 2 400 pairs/s; the same program "
+      "untraced at 5 700-8 900, `bench.py` -> `host_fed.pageable`), so the OVERLAP columns below describe the traced run only. What carries over is the duration of each piece: "
+      "an upload of one 2.2 MB plane 54-55 us (40 GB/s: a copy this small pays ~10 us of fixed cost), the kernel 46 us, a download 45 us -- 201 us of device-side work per pair if "
+      "nothing overlapped, 109 us on the upload engine alone. Untraced the batch takes 112-175 us per pair: the three slots overlap uploads, kernel and downloads by a factor 1.15-1.8, "
+      "and the best runs sit at the upload engine's own limit for two separate 2.2 MB copies per pair (9 100 pairs/s). The page-locked batch path (groups of eight frames, adjacent frames "
+      "as one copy, a stream per direction) is the one that reaches the bus: 10 800-11 600 pairs/s.", ""]
+md += phase(single, "eight synchronous `sadhip_disparity_u8` calls (one pair per call: the WebUI's shape)", 8)
+md += phase(batch, "`sadhip_disparity_batch_u8`, 32 pairs (three slots in flight)", 32)
+md += ["Log of the traced program:", "", "```"] + [l.rstrip() for l in open(os.path.join(d, "trace.log")) if "sadhip_" in l] + ["```", ""]
+open(out, "w").write("\n".join(md))
+print("\n".join(md))
