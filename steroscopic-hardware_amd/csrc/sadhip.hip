@@ -3,7 +3,7 @@
 // H2D / kernel / D2H pipelining.  No CPU compute fallback lives here.
 #include "../../include/sadhip.h"
 #include "sadhip_kernels.h"
-#include "host/copy_gang.h"
+#include "../host/copy_gang.h"
 
 #include <hip/hip_runtime.h>
 #include <pthread.h>

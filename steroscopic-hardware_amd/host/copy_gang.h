@@ -1,4 +1,4 @@
-// copy_gang.h -- the host threads that move caller memory into / out of a context's page-locked planes (sadhip.hip).
+// host/copy_gang.h -- the host threads that move caller memory into / out of a context's page-locked planes (sadhip.hip).
 // Plain C++17, no HIP: tests/test_copy_gang_cpu.py builds it alone under ThreadSanitizer and AddressSanitizer.
 #pragma once
 #include <atomic>

@@ -1,10 +1,10 @@
-// Stress of steroscopic-hardware_amd/csrc/host/copy_gang.h (the threads that stage caller memory through a context's
+// Stress of steroscopic-hardware_amd/host/copy_gang.h (the threads that stage caller memory through a context's
 // page-locked planes) on the CPU, built under ThreadSanitizer and under AddressSanitizer by tests/test_copy_gang_cpu.py.
 // Random row counts, widths and pitches on both sides (whole-row copies and row-by-row copies), sizes either side of
 // the gang's threshold, back-to-back and spaced calls (spin phase / sleep phase of the helpers), several gangs at once,
 // gangs destroyed while their helpers spin; source buffers allocated at EXACTLY the bytes a copy may read
 // ((rows-1)*pitch + wbytes) and destination rows checked for bytes outside the rows.
-#include "../../steroscopic-hardware_amd/csrc/host/copy_gang.h"
+#include "../../steroscopic-hardware_amd/host/copy_gang.h"
 #include <cstdio>
 #include <cstdlib>
 #include <memory>

@@ -1,4 +1,4 @@
-"""The copy threads of the staged host path (steroscopic-hardware_amd/csrc/host/copy_gang.h: plain C++, no HIP) under
+"""The copy threads of the staged host path (steroscopic-hardware_amd/host/copy_gang.h: plain C++, no HIP) under
 ThreadSanitizer and AddressSanitizer + UBSan on the CPU (GPU sanitizers are not available on the pool): the hand-off
 between the calling thread and the helpers (spin phase, sleep phase, shutdown), and the bounds of every copy -- sources
 allocated at exactly the bytes a copy may read, destinations checked for bytes outside their rows."""
@@ -9,7 +9,7 @@ import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "tests", "host", "stress_copy_gang.cpp")
-HDR = os.path.join(REPO, "steroscopic-hardware_amd", "csrc", "host", "copy_gang.h")
+HDR = os.path.join(REPO, "steroscopic-hardware_amd", "host", "copy_gang.h")
 OUT = os.path.join(REPO, "steroscopic-hardware_amd", "lib")
 
 
