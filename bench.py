@@ -272,7 +272,7 @@ def _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, r
         onep = (time.perf_counter() - t0) / min(npg, 16)
         legs["host_fed"]["pageable"] = {"value": npg / dtp, "unit": "pairs/s", "frames": npg, "pcie_gb_per_s": 3 * frame * npg / dtp / 1e9,
                                         "matches_device_resident": okp,
-                                        "note": "the host thread stages every frame through the context's page-locked planes, two frames in flight (the cgo shim's case)"}
+                                        "note": "the host thread stages every frame through the context's page-locked planes with its copy threads, three frames in flight (the cgo shim's case)"}
         legs["host_fed"]["single_call_ms"]["pageable"] = onep * 1e3
         # the native pool (frame i -> device i mod G), same page-locked frames, for G = 1, 2, 4, 8 of the visible devices:
         # SURVEY 8(e) "(ii) host-fed" -- the curve that is expected to flatten at the host's PCIe / memory limit
