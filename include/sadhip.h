@@ -269,6 +269,10 @@ SADHIP_API int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, 
  * ranges and then uses asynchronous linear copies; results are identical either way.  Free / unregister a
  * range only when no call that was given pointers into it is still running (every entry point has finished
  * with the caller's memory when it returns).
+ * Prefer sadhip_host_alloc where the host can choose its frame memory: sadhip_host_register (hipHostRegister) locks the
+ * CALLER's pages in place -- the mechanism the withdrawn pageable path relied on per call; a registration
+ * is long-lived and made once, the way that mechanism is normally used, and has shown no fault here, but its memory must stay
+ * mapped and untouched by free() / munmap() / realloc() until sadhip_host_unregister.
  * The known ranges are DISJOINT page by page: sadhip_host_register of memory that shares a 4 KiB page with a sadhip_host_alloc
  * block or an earlier registration (a sub-range, a super-range, a partial overlap, a neighbour that starts or ends inside the
  * same page) returns SADHIP_ERR_ARG and registers nothing. */
