@@ -14,6 +14,10 @@ import steroscopic_hardware_amd as sha
 from steroscopic_hardware_amd import capi
 if os.environ.get("SADHIP_LIB"): capi.LIB_PATH = os.path.abspath(os.environ["SADHIP_LIB"])
 W, H, B, D, NB = 1920, 1080, 9, 64, 64
+if "--pin" in sys.argv:                                       # the calling thread (before it allocates the frames; the copy threads inherit the mask) on the device's own CPUs
+    place = capi.device_describe(0)
+    if place["cpus"]: os.sched_setaffinity(0, place["cpus"])
+    print("pinned to", len(place["cpus"]), "CPUs of NUMA node", place["numa_node"], flush=True)
 pairs = [sha.synth.synth_pair(100 + i, W, H) for i in range(NB)]
 ls, rs = [p[0] for p in pairs], [p[1] for p in pairs]
 os_ = [np.zeros((H, W), np.uint8) for _ in range(NB)]
@@ -27,7 +31,10 @@ def med(fn, n=30):
         t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
     return sorted(ts)[n // 2] * 1e3, min(ts) * 1e3
 
-modes = [("default", 0, 0)] + [("staged", 8192, t) for t in (1, 2, 4, 6, 8)] + [("staged", kb, 6) for kb in (2048, 1024, 512)] + ([("direct", 0, 1)] if "--direct" in sys.argv else [])
+if "--quick" in sys.argv:
+    modes = [("default", 0, 0), ("default", 0, 0)]
+else:
+  modes = [("default", 0, 0)] + [("staged", 8192, t) for t in (1, 2, 4, 6, 8)] + [("staged", kb, 6) for kb in (2048, 1024, 512)] + ([("direct", 0, 1)] if "--direct" in sys.argv else [])
 for mode, bands, threads in modes:
     if mode == "default":                                    # what the product library does: no knob set
         for k in ("SADHIP_TUNE_HOSTCOPY", "SADHIP_TUNE_BANDKB", "SADHIP_TUNE_COPYTHREADS"): os.environ.pop(k, None)
