@@ -43,7 +43,19 @@ struct Registry {
     return *e;
   }
 };
-Registry& registry() { static Registry r; return r; }
+Registry& registry()
+{
+  // the header this file was compiled against and the library the process loaded must be the same ABI
+  static const bool abi_ok = [] {
+    if (sadhip_abi_version() != SADHIP_ABI_VERSION)
+      throw std::runtime_error("despair: libsadhip ABI " + std::to_string(sadhip_abi_version()) + " loaded, built against " +
+                               std::to_string(SADHIP_ABI_VERSION));
+    return true;
+  }();
+  (void)abi_ok;
+  static Registry r;
+  return r;
+}
 
 class Lease {
  public:

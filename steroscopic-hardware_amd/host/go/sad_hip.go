@@ -60,6 +60,10 @@ var ctx hipCtx
 
 func (c *hipCtx) init() {
 	c.once.Do(func() {
+		// the header this file was compiled against and the library the process loaded must be the same ABI
+		if got := int(C.sadhip_abi_version()); got != int(C.SADHIP_ABI_VERSION) {
+			panic(fmt.Sprintf("despair: libsadhip ABI %d loaded, built against %d", got, int(C.SADHIP_ABI_VERSION)))
+		}
 		if v, err := strconv.Atoi(os.Getenv("SADHIP_DEVICE")); err == nil && v >= 0 {
 			c.device = v
 		}
