@@ -1045,6 +1045,15 @@ def test_pageable_memory_is_staged_in_bands_by_the_copy_threads(ctx):
     # a small frame: below the threshold of the copy threads
     l, r = sha.synth.synth_pair(5, 200, 90)
     assert np.array_equal(ctx.disparity(l, r, 9, 64), _expect(l, r, 9, 64))
+    # two pool workers at once, each with copy threads of its own, frames in pageable memory
+    pairs = [sha.synth.synth_pair(7000 + i, 1920, 1080) for i in range(3)]
+    want = [ctx.disparity(l, r, 9, 64) for l, r in pairs]
+    for (l, r), o in zip(pairs, want):
+        for y0 in (0, 538, 1076):
+            assert np.array_equal(o[y0:y0 + 4], oracle.disparity_rows_mt(l, r, 9, 64, y0, y0 + 4, 8))
+    with capi.Pool([0, 0], 1920, 1080) as pool:
+        outs = pool.batch([pairs[i % 3][0] for i in range(9)], [pairs[i % 3][1] for i in range(9)], 9, 64)
+        assert all(np.array_equal(outs[i], want[i % 3]) for i in range(9))
 
 
 def test_device_resident_batch(ctx):
