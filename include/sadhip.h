@@ -123,6 +123,14 @@ SADHIP_API const char* sadhip_last_error(void);                  /* thread-local
 SADHIP_API int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch, sadhip_ctx** out);
 SADHIP_API int sadhip_ctx_destroy(sadhip_ctx* ctx);
 SADHIP_API int sadhip_ctx_device(const sadhip_ctx* ctx, int* device);
+/* Host threads that copy caller memory which is not page-locked into / out of the context's page-locked planes
+ * (ABI 4): n = 1..32 INCLUDING the calling thread; the default is SADHIP_DEFAULT_COPY_THREADS.  1 = the calling
+ * thread copies alone (no helper threads exist).  The helpers are started by the first copy of 512 KiB or more,
+ * touch host memory only, poll for 150 us after a piece of work and sleep otherwise.  Takes effect from the next
+ * call on the context; SADHIP_ERR_ARG outside 1..32. */
+#define SADHIP_DEFAULT_COPY_THREADS 6
+SADHIP_API int sadhip_ctx_set_copy_threads(sadhip_ctx* ctx, int n);
+SADHIP_API int sadhip_ctx_get_copy_threads(sadhip_ctx* ctx, int* n);
 
 /* ---- whole frame, host buffers (synchronous) ------------------------------------------------
  * Replaces RunSad (sad.go:119-169) and the OutputCamera frame loop
@@ -292,6 +300,8 @@ typedef struct sadhip_pool sadhip_pool;
 SADHIP_API int sadhip_pool_create(const int* devices, int n_devices, int max_w, int max_h, sadhip_pool** out);
 SADHIP_API int sadhip_pool_destroy(sadhip_pool* pool);
 SADHIP_API int sadhip_pool_size(const sadhip_pool* pool, int* n_devices);
+/* sadhip_ctx_set_copy_threads for every entry's context (n per entry, 1..32): eight devices at the default are 48 host threads. */
+SADHIP_API int sadhip_pool_set_copy_threads(sadhip_pool* pool, int n);
 SADHIP_API int sadhip_pool_batch_u8(sadhip_pool* pool, int n,
                          const uint8_t* const* lefts, const uint8_t* const* rights,
                          int w, int h, int lstride, int rstride,

@@ -42,6 +42,8 @@ SYMBOLS = {
     "sadhip_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sadhip_ctx_destroy": (C.c_int, [C.c_void_p]),
     "sadhip_ctx_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "sadhip_ctx_set_copy_threads": (C.c_int, [C.c_void_p, C.c_int]),
+    "sadhip_ctx_get_copy_threads": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "sadhip_disparity_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int]),
     "sadhip_disparity_region_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -71,6 +73,7 @@ SYMBOLS = {
     "sadhip_pool_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sadhip_pool_destroy": (C.c_int, [C.c_void_p]),
     "sadhip_pool_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "sadhip_pool_set_copy_threads": (C.c_int, [C.c_void_p, C.c_int]),
     "sadhip_pool_batch_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
                                        C.POINTER(C.c_void_p), C.c_int]),
@@ -282,6 +285,15 @@ class Context:
             pass
 
     # ---- host-buffer entry points ---------------------------------------------------------
+    def set_copy_threads(self, n):
+        """Host threads (the caller included) that stage frames which are not in page-locked memory: 1..32."""
+        _check(lib().sadhip_ctx_set_copy_threads(self._h, int(n)))
+
+    def copy_threads(self):
+        n = C.c_int(0)
+        _check(lib().sadhip_ctx_get_copy_threads(self._h, C.byref(n)))
+        return n.value
+
     def disparity(self, left, right, block, maxdisp, flags=0, out=None):
         _img(left, "left"), _img(right, "right")
         if left.shape != right.shape:
@@ -455,6 +467,10 @@ class Pool:
         n = C.c_int(0)
         _check(lib().sadhip_pool_size(self._h, C.byref(n)))
         return n.value
+
+    def set_copy_threads(self, n):
+        """Host threads per entry (its worker included) that stage frames which are not in page-locked memory: 1..32."""
+        _check(lib().sadhip_pool_set_copy_threads(self._h, int(n)))
 
     def batch(self, lefts, rights, block, maxdisp, flags=0, outs=None):
         if len(lefts) == 0:

@@ -260,7 +260,8 @@ struct sadhip_ctx {
   // RGBA picture in four.
   bool direct_pageable = false;
   size_t band_bytes = (size_t)8 << 20;
-  static constexpr int kCopyHelpers = 5;       // + the calling thread
+  static constexpr int kCopyHelpers = SADHIP_DEFAULT_COPY_THREADS - 1;       // + the calling thread
+  int copy_helpers = kCopyHelpers;
   std::unique_ptr<CopyGang> gang;
   std::mutex mu;
 };
@@ -372,6 +373,7 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
   if (const char* e = getenv("SADHIP_TUNE_BANDKB")) c->band_bytes = (size_t)std::max(atoi(e), 4) << 10;
   int helpers = sadhip_ctx::kCopyHelpers;
   if (const char* e = getenv("SADHIP_TUNE_COPYTHREADS")) helpers = std::min(std::max(atoi(e), 1), 32) - 1;
+  c->copy_helpers = helpers;
   c->gang.reset(new (std::nothrow) CopyGang(helpers));
 #else
   c->gang.reset(new (std::nothrow) CopyGang(sadhip_ctx::kCopyHelpers));
@@ -400,6 +402,27 @@ extern "C" int sadhip_ctx_destroy(sadhip_ctx* ctx)
 {
   if (!ctx) return fail(SADHIP_ERR_NULL, "ctx is NULL");
   destroy_ctx(ctx);
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_ctx_set_copy_threads(sadhip_ctx* ctx, int n)
+{
+  if (!ctx) return fail(SADHIP_ERR_NULL, "ctx is NULL");
+  if (n < 1 || n > 32) return fail(SADHIP_ERR_ARG, "copy threads n=%d (valid 1..32, the calling thread included)", n);
+  std::lock_guard<std::mutex> lk(ctx->mu);                  // no call is inside a copy
+  if (n - 1 == ctx->copy_helpers && ctx->gang) return SADHIP_OK;
+  CopyGang* g = new (std::nothrow) CopyGang(n - 1);
+  if (!g) return fail(SADHIP_ERR_NOMEM, "copy threads");
+  ctx->gang.reset(g);                                       // joins the old helpers
+  ctx->copy_helpers = n - 1;
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_ctx_get_copy_threads(sadhip_ctx* ctx, int* n)
+{
+  if (!ctx || !n) return fail(SADHIP_ERR_NULL, "ctx or n is NULL");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *n = ctx->copy_helpers + 1;
   return SADHIP_OK;
 }
 
@@ -1329,6 +1352,14 @@ extern "C" int sadhip_pool_size(const sadhip_pool* pool, int* n_devices)
 {
   if (!pool || !n_devices) return fail(SADHIP_ERR_NULL, "pool or n_devices is NULL");
   *n_devices = (int)pool->w.size();
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_pool_set_copy_threads(sadhip_pool* pool, int n)
+{
+  if (!pool) return fail(SADHIP_ERR_NULL, "pool is NULL");
+  for (auto& w : pool->w)
+    if (int st = sadhip_ctx_set_copy_threads(w->ctx, n)) return st;
   return SADHIP_OK;
 }
 

@@ -73,6 +73,8 @@ int sadhip_ctx_destroy(sadhip_ctx* c)
   return SADHIP_OK;
 }
 int sadhip_ctx_device(const sadhip_ctx* c, int* d) { *d = c->device; return SADHIP_OK; }
+int sadhip_ctx_set_copy_threads(sadhip_ctx*, int n) { return n >= 1 && n <= 32 ? SADHIP_OK : SADHIP_ERR_ARG; }
+int sadhip_ctx_get_copy_threads(sadhip_ctx*, int* n) { *n = SADHIP_DEFAULT_COPY_THREADS; return SADHIP_OK; }
 
 int sadhip_disparity_region_u8(sadhip_ctx* c, const uint8_t* L, const uint8_t* R, int w, int h, int ls, int rs,
                                int block, int maxdisp, unsigned, int x0, int y0, int x1, int y1, uint8_t* out)
@@ -148,6 +150,7 @@ int sadhip_pool_create(const int* devices, int n, int w, int h, sadhip_pool** ou
 }
 int sadhip_pool_destroy(sadhip_pool* p) { for (int i = 0; i < p->n; ++i) sadhip_ctx_destroy(p->ctx[i]); return SADHIP_OK; }
 int sadhip_pool_size(const sadhip_pool* p, int* n) { *n = p->n; return SADHIP_OK; }
+int sadhip_pool_set_copy_threads(sadhip_pool*, int n) { return n >= 1 && n <= 32 ? SADHIP_OK : SADHIP_ERR_ARG; }
 int sadhip_pool_batch_u8(sadhip_pool* p, int n, const uint8_t* const* ls, const uint8_t* const* rs, int w, int h, int lst, int rst,
                          int block, int maxdisp, unsigned flags, uint8_t* const* outs, int os)
 {

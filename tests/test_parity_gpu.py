@@ -1045,6 +1045,18 @@ def test_pageable_memory_is_staged_in_bands_by_the_copy_threads(ctx):
     # a small frame: below the threshold of the copy threads
     l, r = sha.synth.synth_pair(5, 200, 90)
     assert np.array_equal(ctx.disparity(l, r, 9, 64), _expect(l, r, 9, 64))
+    # the number of copy threads is the host's to choose (sadhip_ctx_set_copy_threads): same bytes with 1, 2, 32 and back
+    assert ctx.copy_threads() == 6
+    l1, r1 = sha.synth.synth_pair(7100, 1920, 1080)
+    ref6 = ctx.disparity(l1, r1, 9, 64)
+    for n in (1, 2, 32, 6):
+        ctx.set_copy_threads(n)
+        assert ctx.copy_threads() == n
+        assert np.array_equal(ctx.disparity(l1, r1, 9, 64), ref6), n
+    for n in (0, 33, -1):
+        with pytest.raises(capi.SadHipError) as ei:
+            ctx.set_copy_threads(n)
+        assert ei.value.status == capi.ERR_ARG and ctx.copy_threads() == 6
     # two pool workers at once, each with copy threads of its own, frames in pageable memory
     pairs = [sha.synth.synth_pair(7000 + i, 1920, 1080) for i in range(3)]
     want = [ctx.disparity(l, r, 9, 64) for l, r in pairs]
@@ -1054,6 +1066,11 @@ def test_pageable_memory_is_staged_in_bands_by_the_copy_threads(ctx):
     with capi.Pool([0, 0], 1920, 1080) as pool:
         outs = pool.batch([pairs[i % 3][0] for i in range(9)], [pairs[i % 3][1] for i in range(9)], 9, 64)
         assert all(np.array_equal(outs[i], want[i % 3]) for i in range(9))
+        pool.set_copy_threads(2)
+        outs = pool.batch([pairs[i % 3][0] for i in range(5)], [pairs[i % 3][1] for i in range(5)], 9, 64)
+        assert all(np.array_equal(outs[i], want[i % 3]) for i in range(5))
+        with pytest.raises(capi.SadHipError):
+            pool.set_copy_threads(0)
 
 
 def test_device_resident_batch(ctx):
