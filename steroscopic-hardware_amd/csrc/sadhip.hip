@@ -370,6 +370,7 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
   c->plane = c->pitch * (size_t)max_h;
 #ifdef SADHIP_TUNING
   if (const char* e = getenv("SADHIP_TUNE_HOSTCOPY")) c->direct_pageable = strcmp(e, "direct") == 0;
+  if (const char* e = getenv("SADHIP_TUNE_STREAM")) sadhip::stream_stores() = atoi(e) != 0;
   if (const char* e = getenv("SADHIP_TUNE_BANDKB")) c->band_bytes = (size_t)std::max(atoi(e), 4) << 10;
   int helpers = sadhip_ctx::kCopyHelpers;
   if (const char* e = getenv("SADHIP_TUNE_COPYTHREADS")) helpers = std::min(std::max(atoi(e), 1), 32) - 1;

@@ -6,6 +6,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <emmintrin.h>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -24,14 +25,38 @@ struct RowCopy {
   bool whole_rows;           // the bytes between the rows may be copied too (dst is a plane of ours, src readable to its last row's wbytes)
 };
 
+// memcpy with non-temporal stores for the 16-byte-aligned body of the destination (SSE2: every x86-64 has it).  A staged
+// frame is written once and read next by a copy engine (upload) or never again by this thread (download): ordinary stores
+// would first READ every destination line into the cache (a third of the memory traffic of the copy) and push the caller's
+// working set out of it.  Pieces below kStreamMin go through memcpy.  copy_rows_* end with an sfence: the stores are
+// globally visible before the thread reports its piece done.
+constexpr size_t kStreamMin = 1024;
+inline bool& stream_stores() { static bool on = true; return on; }      // (switched off by the diagnostics build for the A/B)
+
+inline void copy_stream(uint8_t* dst, const uint8_t* src, size_t n)
+{
+  if (n < kStreamMin || !stream_stores()) { memcpy(dst, src, n); return; }
+  const size_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+  if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+  size_t blocks = n / 64;
+  for (; blocks; --blocks, dst += 64, src += 64) {
+    const __m128i a = _mm_loadu_si128((const __m128i*)src), b = _mm_loadu_si128((const __m128i*)(src + 16));
+    const __m128i c = _mm_loadu_si128((const __m128i*)(src + 32)), d = _mm_loadu_si128((const __m128i*)(src + 48));
+    _mm_stream_si128((__m128i*)dst, a); _mm_stream_si128((__m128i*)(dst + 16), b);
+    _mm_stream_si128((__m128i*)(dst + 32), c); _mm_stream_si128((__m128i*)(dst + 48), d);
+  }
+  if (n & 63) memcpy(dst, src, n & 63);
+}
+
 inline void copy_part(const RowCopy& c, int r0, int r1)
 {
   if (r1 <= r0) return;
   if (c.dpitch == c.spitch && (c.wbytes == c.dpitch || c.whole_rows)) {
-    memcpy(c.dst + (size_t)r0 * c.dpitch, c.src + (size_t)r0 * c.spitch, (size_t)(r1 - r0 - 1) * c.dpitch + c.wbytes);
-    return;
+    copy_stream(c.dst + (size_t)r0 * c.dpitch, c.src + (size_t)r0 * c.spitch, (size_t)(r1 - r0 - 1) * c.dpitch + c.wbytes);
+  } else {
+    for (int r = r0; r < r1; ++r) copy_stream(c.dst + (size_t)r * c.dpitch, c.src + (size_t)r * c.spitch, c.wbytes);
   }
-  for (int r = r0; r < r1; ++r) memcpy(c.dst + (size_t)r * c.dpitch, c.src + (size_t)r * c.spitch, c.wbytes);
+  _mm_sfence();
 }
 
 class CopyGang {
