@@ -206,7 +206,13 @@ struct Slot {            // one pipeline stage worth of buffers (one frame)
   uint8_t *hL = nullptr, *hR = nullptr, *hO = nullptr;   // pinned host staging
   uint8_t *dL = nullptr, *dR = nullptr, *dO = nullptr;   // device planes
   hipStream_t stream = nullptr;
+  // where the frame in flight runs: all three the slot's own stream for a single call; the context's per-direction streams
+  // (s_up / s_kern / s_down) for a staged batch, chained by `uploaded` and k1 -- uploads, kernels and downloads of one stream
+  // share a copy engine and serialise, and on some boxes of the pool three slot streams did not overlap at all (204 us per
+  // pair = upload + kernel + download laid end to end, profiles/r04_ab_hostcopy_stream_stores.txt)
+  hipStream_t up = nullptr, kern = nullptr, down = nullptr;
   hipEvent_t k0 = nullptr, k1 = nullptr;                 // kernel begin / end
+  hipEvent_t uploaded = nullptr, done = nullptr;         // inputs on the device / result delivered (or in hO)
   static constexpr int kMaxBands = 4;
   hipEvent_t band[kMaxBands] = {};                       // band b of a staged result has arrived in hO
   uint8_t* out = nullptr; int ostride = 0;               // where the frame in flight delivers (route_output)
@@ -300,6 +306,8 @@ static void destroy_ctx(sadhip_ctx* c)
     if (s.dO) (void)hipFree(s.dO);
     if (s.k0) (void)hipEventDestroy(s.k0);
     if (s.k1) (void)hipEventDestroy(s.k1);
+    if (s.uploaded) (void)hipEventDestroy(s.uploaded);
+    if (s.done) (void)hipEventDestroy(s.done);
     for (auto& b : s.band) if (b) (void)hipEventDestroy(b);
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
@@ -322,12 +330,22 @@ static void destroy_groups(sadhip_ctx* c)
   c->grp_ready = false;
 }
 
+// one stream per direction (uploads / kernels / downloads), shared by the page-locked group pipeline and the staged batch
+static int ensure_dir_streams(sadhip_ctx* c)
+{
+  for (hipStream_t* st : {&c->s_up, &c->s_kern, &c->s_down})
+    if (!*st) {
+      const hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+      if (e != hipSuccess) { *st = nullptr; return fail(SADHIP_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e)); }
+    }
+  return SADHIP_OK;
+}
+
 static int ensure_groups(sadhip_ctx* c)
 {
   if (c->grp_ready) return SADHIP_OK;
-  hipError_t e = hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_kern, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking);
+  if (int st = ensure_dir_streams(c)) return st;
+  hipError_t e = hipSuccess;
   for (auto& g : c->grp) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g.up, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g.down, hipEventDisableTiming);
@@ -384,6 +402,9 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&s.k0);
     if (e == hipSuccess) e = hipEventCreate(&s.k1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    s.up = s.kern = s.down = s.stream;
     for (auto& b : s.band) if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dL, c->plane);
     if (e == hipSuccess) e = hipMalloc((void**)&s.dR, c->plane);
@@ -584,16 +605,16 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
                       is_pinned(left + (size_t)band0 * lstride, lbytes) && (rbytes == 0 || is_pinned(right + (size_t)band0 * rstride, rbytes));
   if (pinned) {
     dl = (size_t)lstride; dr = (size_t)rstride;
-    HIPTRY(hipMemcpyAsync(s.dL, left + (size_t)band0 * lstride, lbytes, hipMemcpyHostToDevice, s.stream));
-    if (rbytes) HIPTRY(hipMemcpyAsync(s.dR, right + (size_t)band0 * rstride, rbytes, hipMemcpyHostToDevice, s.stream));
+    HIPTRY(hipMemcpyAsync(s.dL, left + (size_t)band0 * lstride, lbytes, hipMemcpyHostToDevice, s.up));
+    if (rbytes) HIPTRY(hipMemcpyAsync(s.dR, right + (size_t)band0 * rstride, rbytes, hipMemcpyHostToDevice, s.up));
   } else if (c->direct_pageable) {                         // diagnostics build only: the runtime locks the caller's pages
-    HIPTRY(hipMemcpy2DAsync(s.dL, pitch, left + (size_t)band0 * lstride, lstride, w, band1 - band0, hipMemcpyHostToDevice, s.stream));
+    HIPTRY(hipMemcpy2DAsync(s.dL, pitch, left + (size_t)band0 * lstride, lstride, w, band1 - band0, hipMemcpyHostToDevice, s.up));
     if (rband1 > band0)
-      HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, rw, rband1 - band0, hipMemcpyHostToDevice, s.stream));
+      HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, rw, rband1 - band0, hipMemcpyHostToDevice, s.up));
   } else {
     if (int st = ensure_stage(c, s)) return st;
-    if (int st = upload_staged(c, s.stream, s.dL, s.hL, pitch, left, (size_t)lstride, (size_t)w, band0, band1)) return st;
-    if (int st = upload_staged(c, s.stream, s.dR, s.hR, pitch, right, (size_t)rstride, (size_t)rw, band0, rband1)) return st;
+    if (int st = upload_staged(c, s.up, s.dL, s.hL, pitch, left, (size_t)lstride, (size_t)w, band0, band1)) return st;
+    if (int st = upload_staged(c, s.up, s.dR, s.hR, pitch, right, (size_t)rstride, (size_t)rw, band0, rband1)) return st;
   }
   Job j{};
   j.left = s.dL; j.right = s.dR; j.out = s.dO;
@@ -605,9 +626,13 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
   j.ox = 0; j.oy = y0;            // staging output: row 0 = image row y0, full-width rows
   j.raw = (flags & SADHIP_FLAG_RAW) ? 1 : 0;
   j.row0 = band0;
-  HIPTRY(hipEventRecord(s.k0, s.stream));
-  HIPTRY(dispatch(j, flags, s.stream));
-  HIPTRY(hipEventRecord(s.k1, s.stream));
+  if (s.kern != s.up) {
+    HIPTRY(hipEventRecord(s.uploaded, s.up));
+    HIPTRY(hipStreamWaitEvent(s.kern, s.uploaded, 0));
+  }
+  HIPTRY(hipEventRecord(s.k0, s.kern));
+  HIPTRY(dispatch(j, flags, s.kern));
+  HIPTRY(hipEventRecord(s.k1, s.kern));
   return enqueue_download(c, s, w, x0, x1, y1 - y0);
 }
 
@@ -616,17 +641,20 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
 static int enqueue_download(sadhip_ctx* c, Slot& s, int w, int x0, int x1, int rows)
 {
   const size_t pitch = pitch_for(w);
+  if (s.down != s.kern) HIPTRY(hipStreamWaitEvent(s.down, s.k1, 0));
   if (s.out_direct) {
-    HIPTRY(hipMemcpy2DAsync(s.out, s.ostride, s.dO + x0, pitch, x1 - x0, rows, hipMemcpyDeviceToHost, s.stream));
+    HIPTRY(hipMemcpy2DAsync(s.out, s.ostride, s.dO + x0, pitch, x1 - x0, rows, hipMemcpyDeviceToHost, s.down));
+    HIPTRY(hipEventRecord(s.done, s.down));
     return SADHIP_OK;
   }
   if (int st = ensure_stage(c, s)) return st;
   s.out_bands = band_count(rows, pitch, c->band_bytes);
   for (int b = 0; b < s.out_bands; ++b) {
     const int a0 = band_row(0, rows, s.out_bands, b), a1 = band_row(0, rows, s.out_bands, b + 1);
-    HIPTRY(hipMemcpyAsync(s.hO + (size_t)a0 * pitch, s.dO + (size_t)a0 * pitch, (size_t)(a1 - a0) * pitch, hipMemcpyDeviceToHost, s.stream));
-    HIPTRY(hipEventRecord(s.band[b], s.stream));
+    HIPTRY(hipMemcpyAsync(s.hO + (size_t)a0 * pitch, s.dO + (size_t)a0 * pitch, (size_t)(a1 - a0) * pitch, hipMemcpyDeviceToHost, s.down));
+    HIPTRY(hipEventRecord(s.band[b], s.down));
   }
+  HIPTRY(hipEventRecord(s.done, s.down));
   return SADHIP_OK;
 }
 
@@ -643,7 +671,7 @@ static int finish_frame(sadhip_ctx* c, Slot& s, int w, int x0, int y0, int x1, i
       // never a byte outside the caller's rw-byte rows
       copy_rows(c, RowCopy{out + (size_t)a0 * ostride, (size_t)ostride, s.hO + (size_t)a0 * pitch + x0, pitch, (size_t)rw, false}, a1 - a0);
     }
-  HIPTRY(hipStreamSynchronize(s.stream));
+  HIPTRY(hipEventSynchronize(s.done));                     // (after the kernel's end on whichever stream ran it)
   float ms = 0.f;
   HIPTRY(hipEventElapsedTime(&ms, s.k0, s.k1));
   if (kernel_ms) *kernel_ms += ms;
@@ -884,19 +912,36 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
     return SADHIP_OK;
   }
   constexpr int S = sadhip_ctx::kSlots;
+  // the frames of a batch run on the per-direction streams (Slot::up / kern / down), chained by events per slot
+  if (int st = ensure_dir_streams(ctx)) return st;
+  struct Route {
+    sadhip_ctx* c;
+    explicit Route(sadhip_ctx* cc) : c(cc)
+    {
+#ifdef SADHIP_TUNING
+      if (getenv("SADHIP_TUNE_SLOTSTREAMS")) return;          // A/B: every slot on its own stream, as before
+#endif
+      for (auto& s : c->slot) { s.up = c->s_up; s.kern = c->s_kern; s.down = c->s_down; }
+    }
+    ~Route() { for (auto& s : c->slot) s.up = s.kern = s.down = s.stream; }
+  } route(ctx);
+  auto drain = [&] {                                       // error exit: nothing of the caller's stays in flight
+    for (hipStream_t st : {ctx->s_up, ctx->s_kern, ctx->s_down}) (void)hipStreamSynchronize(st);
+    for (auto& s : ctx->slot) (void)hipStreamSynchronize(s.stream);
+  };
   for (int i = 0; i < n + S - 1; ++i) {
     if (i < n) {
       route_output(ctx, ctx->slot[i % S], outs[i], ostride, w, h);
       if (int st = enqueue_frame(ctx, ctx->slot[i % S], lefts[i], rights[i], w, h, lstride, rstride,
                                  block, maxdisp, flags, 0, 0, w, h, 0, h)) {
-        for (auto& s : ctx->slot) (void)hipStreamSynchronize(s.stream);
+        drain();
         return st;
       }
     }
     const int d = i - (S - 1);
     if (d >= 0) {
       if (int st = finish_frame(ctx, ctx->slot[d % S], w, 0, 0, w, h, &kms)) {
-        for (auto& s : ctx->slot) (void)hipStreamSynchronize(s.stream);
+        drain();
         return st;
       }
     }
