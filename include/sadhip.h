@@ -179,7 +179,7 @@ SADHIP_API int sadhip_disparity_lr_u8(sadhip_ctx* ctx,
 
 /* ---- batch of independent frames, host buffers (synchronous; pipelined inside) --------------
  * Replaces the streaming loop of examples/run.stream.go:30-59 / BASELINE config 4: n independent
- * pairs (any n >= 0), H2D / kernel / D2H pipelined over the context's three slots, a stream each (the host
+ * pairs (any n >= 0), H2D / kernel / D2H pipelined over the context's three slots on one stream per direction (the host
  * thread stages frame i+1 while frame i is on the device), nothing is retained after return.
  * When every frame of the batch lies in page-locked memory this library knows (sadhip_host_alloc /
  * sadhip_host_register below), the batch runs as groups of frames per kernel launch with truly
