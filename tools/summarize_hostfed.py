@@ -57,12 +57,12 @@ single = sorted(ks + [e for e in cp if e[2] > kr[0][2] and e[1] < kr[9][1] - 100
 md = ["# Host-fed entry points under `rocprofv3 --kernel-trace --memory-copy-trace` (no counters)", "",
       "`tools/trace_hostfed.sh` -> `tools/bench_hostfed.py`: 1920x1080, BlockSize 9, MaxDisparity 64, frames in pageable numpy memory -- the staged path: the context's copy threads fill / empty page-locked planes, the copy engines only ever see those.", "",
       f"Trace totals: {len(cp)} copies, {nk} disparity kernels.", "",
-      "**Read the spans with care**: the copy tracer completes every copy before the next one starts on this stack (the traced batch runs at 2 400 pairs/s; the same program "
-      "untraced at 5 700-8 900, `bench.py` -> `host_fed.pageable`), so the OVERLAP columns below describe the traced run only. What carries over is the duration of each piece: "
+      "**Read the spans with care**: the copy tracer completes every copy before the next one starts on this stack (the traced batch runs at 2 400 pairs/s, the same program "
+      "untraced at 4 700-8 900 with one stream per slot -- the arrangement this trace was taken with -- and at 8 000-8 600 with one stream per direction, `bench.py` -> `host_fed.pageable`), "
+      "so the OVERLAP columns below describe the traced run only. What carries over is the duration of each piece: "
       "an upload of one 2.2 MB plane 54-55 us (40 GB/s: a copy this small pays ~10 us of fixed cost), the kernel 46 us, a download 45 us -- 201 us of device-side work per pair if "
-      "nothing overlapped, 109 us on the upload engine alone. Untraced the batch takes 112-175 us per pair: the three slots overlap uploads, kernel and downloads by a factor 1.15-1.8, "
-      "and the best runs sit at the upload engine's own limit for two separate 2.2 MB copies per pair (9 100 pairs/s). The page-locked batch path (groups of eight frames, adjacent frames "
-      "as one copy, a stream per direction) is the one that reaches the bus: 10 800-11 600 pairs/s.", ""]
+      "nothing overlaps (which is what boxes with 4 700-5 000 pairs/s were doing, and why the batch moved to per-direction streams: `profiles/r04_ab_hostcopy_dirstreams.txt`), 109 us on the "
+      "upload engine alone (9 100 pairs/s). The page-locked batch path (groups of eight frames, adjacent frames as one copy) is the one that reaches the bus: 10 800-11 700 pairs/s.", ""]
 md += phase(single, "eight synchronous `sadhip_disparity_u8` calls (one pair per call: the WebUI's shape)", 8)
 md += phase(batch, "`sadhip_disparity_batch_u8`, 32 pairs (three slots in flight)", 32)
 md += ["Log of the traced program:", "", "```"] + [l.rstrip() for l in open(os.path.join(d, "trace.log")) if "sadhip_" in l] + ["```", ""]
