@@ -265,6 +265,7 @@ struct sadhip_ctx {
   // sadhip_disparity_rgba_u8 0.55 ms at 8 MB, 0.63 at 2 MB): a 1080p plane or decoded picture goes in one piece, a 4K
   // RGBA picture in four.
   bool direct_pageable = false;
+  bool pair_upload = true;                     // a staged pair of a batch travels as one upload (diagnostics build: SADHIP_TUNE_PAIRUP=0)
   size_t band_bytes = (size_t)8 << 20;
   static constexpr int kCopyHelpers = SADHIP_DEFAULT_COPY_THREADS - 1;       // + the calling thread
   int copy_helpers = kCopyHelpers;
@@ -298,11 +299,9 @@ static void destroy_ctx(sadhip_ctx* c)
   destroy_groups(c);
   for (auto& s : c->slot) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
-    if (s.hL) (void)hipHostFree(s.hL);
-    if (s.hR) (void)hipHostFree(s.hR);
+    if (s.hL) (void)hipHostFree(s.hL);                       // (hR lives in the same block)
     if (s.hO) (void)hipHostFree(s.hO);
-    if (s.dL) (void)hipFree(s.dL);
-    if (s.dR) (void)hipFree(s.dR);
+    if (s.dL) (void)hipFree(s.dL);                           // (dR lives in the same block)
     if (s.dO) (void)hipFree(s.dO);
     if (s.k0) (void)hipEventDestroy(s.k0);
     if (s.k1) (void)hipEventDestroy(s.k1);
@@ -389,6 +388,7 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
 #ifdef SADHIP_TUNING
   if (const char* e = getenv("SADHIP_TUNE_HOSTCOPY")) c->direct_pageable = strcmp(e, "direct") == 0;
   if (const char* e = getenv("SADHIP_TUNE_STREAM")) sadhip::stream_stores() = atoi(e) != 0;
+  if (const char* e = getenv("SADHIP_TUNE_PAIRUP")) c->pair_upload = atoi(e) != 0;
   if (const char* e = getenv("SADHIP_TUNE_BANDKB")) c->band_bytes = (size_t)std::max(atoi(e), 4) << 10;
   int helpers = sadhip_ctx::kCopyHelpers;
   if (const char* e = getenv("SADHIP_TUNE_COPYTHREADS")) helpers = std::min(std::max(atoi(e), 1), 32) - 1;
@@ -406,8 +406,8 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
     s.up = s.kern = s.down = s.stream;
     for (auto& b : s.band) if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&s.dL, c->plane);
-    if (e == hipSuccess) e = hipMalloc((void**)&s.dR, c->plane);
+    if (e == hipSuccess) e = hipMalloc((void**)&s.dL, 2 * c->plane);      // L and R planes in one block: a staged pair can
+    if (e == hipSuccess) s.dR = s.dL + c->plane;                          // travel as ONE upload (enqueue_frame)
     if (e == hipSuccess) e = hipMalloc((void**)&s.dO, c->plane);
     if (e != hipSuccess) {
       int st = fail(e == hipErrorOutOfMemory ? SADHIP_ERR_NOMEM : SADHIP_ERR_HIP,
@@ -539,14 +539,16 @@ static inline int band_row(int r0, int r1, int nb, int b) { return r0 + (int)((l
 // sees device-resident or page-locked frames never locks host memory of its own)
 static int ensure_stage(sadhip_ctx* c, Slot& s)
 {
-  for (uint8_t** p : {&s.hL, &s.hR, &s.hO})
-    if (!*p) {
-      const hipError_t e = hipHostMalloc((void**)p, c->plane, hipHostMallocDefault);
+  struct { uint8_t** p; size_t bytes; } want[] = {{&s.hL, 2 * c->plane}, {&s.hO, c->plane}};     // hL + hR in one block, like dL + dR
+  for (auto& w : want)
+    if (!*w.p) {
+      const hipError_t e = hipHostMalloc((void**)w.p, w.bytes, hipHostMallocDefault);
       if (e != hipSuccess) {
-        *p = nullptr;
-        return fail(e == hipErrorOutOfMemory ? SADHIP_ERR_NOMEM : SADHIP_ERR_HIP, "page-locked staging plane (%zu B): %s", c->plane, hipGetErrorString(e));
+        *w.p = nullptr;
+        return fail(e == hipErrorOutOfMemory ? SADHIP_ERR_NOMEM : SADHIP_ERR_HIP, "page-locked staging plane (%zu B): %s", w.bytes, hipGetErrorString(e));
       }
     }
+  s.hR = s.hL + c->plane;
   return SADHIP_OK;
 }
 
@@ -599,6 +601,7 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
   // Page-locked inputs this library knows (sadhip_host_*): one asynchronous linear copy per image, the device rows
   // keep the caller's stride (nothing is staged and the host thread does not wait for the bus).
   size_t dl = pitch, dr = pitch;                           // device row strides
+  const uint8_t* dright = s.dR;                            // where the right rows land on the device
   const size_t lbytes = (size_t)(band1 - band0 - 1) * lstride + w;
   const size_t rbytes = rband1 > band0 ? (size_t)(rband1 - band0 - 1) * rstride + rw : 0;
   const bool pinned = (size_t)lstride * (band1 - band0) <= c->plane && (size_t)rstride * (band1 - band0) <= c->plane &&
@@ -613,11 +616,24 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
       HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, rw, rband1 - band0, hipMemcpyHostToDevice, s.up));
   } else {
     if (int st = ensure_stage(c, s)) return st;
-    if (int st = upload_staged(c, s.up, s.dL, s.hL, pitch, left, (size_t)lstride, (size_t)w, band0, band1)) return st;
-    if (int st = upload_staged(c, s.up, s.dR, s.hR, pitch, right, (size_t)rstride, (size_t)rw, band0, rband1)) return st;
+    const int lrows = band1 - band0, rrows = rband1 - band0;
+    if (s.up != s.stream && c->pair_upload && rrows > 0 && band_count(lrows, pitch, c->band_bytes) == 1 &&
+        band_count(rrows, pitch, c->band_bytes) == 1) {
+      // a frame of a batch: the right rows right behind the left ones, the pair as ONE upload -- a 2.2 MB copy costs 54 us of
+      // which ~10 are fixed, and two of them per pair were the upload stream's limit (9 100 pairs/s at 1080p).  Not for a
+      // single call: there the left plane's transfer overlaps the staging of the right one.
+      const size_t used = (size_t)lrows * pitch;
+      copy_rows(c, RowCopy{s.hL, pitch, left + (size_t)band0 * lstride, (size_t)lstride, (size_t)w, true}, lrows);
+      copy_rows(c, RowCopy{s.hL + used, pitch, right + (size_t)band0 * rstride, (size_t)rstride, (size_t)rw, true}, rrows);
+      HIPTRY(hipMemcpyAsync(s.dL, s.hL, used + (size_t)rrows * pitch, hipMemcpyHostToDevice, s.up));
+      dright = s.dL + used;
+    } else {
+      if (int st = upload_staged(c, s.up, s.dL, s.hL, pitch, left, (size_t)lstride, (size_t)w, band0, band1)) return st;
+      if (int st = upload_staged(c, s.up, s.dR, s.hR, pitch, right, (size_t)rstride, (size_t)rw, band0, rband1)) return st;
+    }
   }
   Job j{};
-  j.left = s.dL; j.right = s.dR; j.out = s.dO;
+  j.left = s.dL; j.right = dright; j.out = s.dO;
   j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = c->plane;
   j.lstride = (int)dl; j.rstride = (int)dr; j.ostride = (int)pitch;
   j.n = 1; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;

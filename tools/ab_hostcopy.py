@@ -31,7 +31,9 @@ def med(fn, n=30):
         t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
     return sorted(ts)[n // 2] * 1e3, min(ts) * 1e3
 
-if "--dirstreams" in sys.argv:                                # staged batch on per-direction streams (default) or one stream per slot
+if "--pairup" in sys.argv:                                    # a staged pair of a batch as one upload (default) or as two
+    modes = [("default", 0, 0), ("twouploads", 0, 0), ("default", 0, 0), ("twouploads", 0, 0)]
+elif "--dirstreams" in sys.argv:                                # staged batch on per-direction streams (default) or one stream per slot
     modes = [("default", 0, 0), ("slotstreams", 0, 0), ("default", 0, 0), ("slotstreams", 0, 0)]
 elif "--stream" in sys.argv:                                    # non-temporal stores in the staged copies on / off (SADHIP_TUNE_STREAM)
     modes = [("default", 0, 0), ("nostream", 0, 0), ("default", 0, 0), ("nostream", 0, 0)]
@@ -40,8 +42,9 @@ elif "--quick" in sys.argv:
 else:
   modes = [("default", 0, 0)] + [("staged", 8192, t) for t in (1, 2, 4, 6, 8)] + [("staged", kb, 6) for kb in (2048, 1024, 512)] + ([("direct", 0, 1)] if "--direct" in sys.argv else [])
 for mode, bands, threads in modes:
-    if mode in ("default", "nostream", "slotstreams"):                      # what the product library does: no knob set
-        for k in ("SADHIP_TUNE_HOSTCOPY", "SADHIP_TUNE_BANDKB", "SADHIP_TUNE_COPYTHREADS", "SADHIP_TUNE_STREAM", "SADHIP_TUNE_SLOTSTREAMS"): os.environ.pop(k, None)
+    if mode in ("default", "nostream", "slotstreams", "twouploads"):                      # what the product library does: no knob set
+        for k in ("SADHIP_TUNE_HOSTCOPY", "SADHIP_TUNE_BANDKB", "SADHIP_TUNE_COPYTHREADS", "SADHIP_TUNE_STREAM", "SADHIP_TUNE_SLOTSTREAMS", "SADHIP_TUNE_PAIRUP"): os.environ.pop(k, None)
+        if mode == "twouploads": os.environ["SADHIP_TUNE_PAIRUP"] = "0"
         if mode == "slotstreams": os.environ["SADHIP_TUNE_SLOTSTREAMS"] = "1"
         if mode == "nostream": os.environ["SADHIP_TUNE_STREAM"] = "0"
     else:
