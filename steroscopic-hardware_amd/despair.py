@@ -83,6 +83,18 @@ class Chan:
     def close(self):
         self._q.put(_CLOSED)
 
+    def try_recv(self):
+        """What is queued right now, without waiting: (True, value), or (False, None) when nothing is (a close marker stays
+        queued for the iterating consumer)."""
+        try:
+            v = self._q.get_nowait()
+        except queue.Empty:
+            return False, None
+        if v is _CLOSED:
+            self._q.put(_CLOSED)
+            return False, None
+        return True, v
+
     def __iter__(self):
         while True:
             v = self._q.get()
@@ -118,36 +130,72 @@ def _context(w, h):
 
 def SetupConcurrentSAD(numWorkers):
     """sad.go:29-113.  Returns (inputChan, outputChan).  One device worker replaces the
-    goroutine pool; parameters are snapshotted per chunk (sad.go:51-53); closing the input
+    goroutine pool; parameters are snapshotted per group of chunks that were queued together (sad.go:51-53: the
+    reference's workers would each take theirs within the same microseconds); closing the input
     channel stops the worker, which then closes the output channel (sad.go:106-110).
     On a device error the worker records it in outputChan.error, closes the output channel and
     keeps draining the input channel, so a feeder blocked in send() is released and
     AssembleDisparityMap raises instead of returning a short map."""
     if numWorkers <= 0:
         numWorkers = 32
-    inp, outp = Chan(numWorkers * 2), Chan(numWorkers * 2)
+    # sad.go:36-37: 2 x numWorkers slots each, plus one chunk held by every goroutine that waits to send = 5 x numWorkers
+    # chunks under way before anyone reads -- examples/run.stream.go:46-58 feeds a whole frame (160 chunks for 640x480 with
+    # 32 workers) before it reads.  One device worker holds no crowd: the output channel gets the goroutines' share.
+    inp, outp = Chan(numWorkers * 2), Chan(numWorkers * 3)
+
+    MAX_GROUP = 512                                            # chunks answered by one device call
 
     def worker():
         failed = False
+        pending = None
+        it = iter(inp)
         try:
-            for chunk in inp:
+            while True:
+                if pending is not None:
+                    chunk, pending = pending, None
+                else:
+                    try:
+                        chunk = next(it)
+                    except StopIteration:
+                        break
                 if failed:
                     continue                                   # drain: never leave the feeder blocked
+                # the chunks already queued behind this one that continue it downwards (same images, same columns):
+                # one device call over their common rows, one answer per chunk (host/despair.hpp has the argument)
+                group = [chunk]
+                while len(group) < MAX_GROUP:
+                    ok, nxt = inp.try_recv()
+                    if not ok:
+                        break
+                    f, l = group[0], group[-1]
+                    if (nxt.Left is f.Left and nxt.Right is f.Right and nxt.Region[0] == f.Region[0] and nxt.Region[2] == f.Region[2]
+                            and nxt.Region[1] == l.Region[3] and nxt.Region[3] > nxt.Region[1] and l.Region[3] > l.Region[1]):
+                        group.append(nxt)
+                    else:
+                        pending = nxt                          # starts the next group
+                        break
                 with _default_params_mu:
-                    p = Parameters(_default_params.BlockSize, _default_params.MaxDisparity)
+                    p = Parameters(_default_params.BlockSize, _default_params.MaxDisparity)   # sad.go:51-53, once per group
                 h, w = chunk.Left.shape
+                x0, y0, x1 = group[0].Region[0], group[0].Region[1], group[0].Region[2]
+                allr = (x0, y0, x1, group[-1].Region[3])
                 try:
-                    with _context(w, h) as c:
-                        if chunk.Right.shape == chunk.Left.shape:
-                            data = c.disparity_region(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity, chunk.Region)
-                        else:       # independently decoded pictures (output.go:134-162): the reference's clamps, sad.go:212-233
-                            data = c.disparity_lr(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity, chunk.Region)
+                    if allr[2] <= allr[0] or allr[3] <= allr[1]:
+                        data = np.zeros((max(allr[3] - allr[1], 0), max(allr[2] - allr[0], 0)), np.uint8)   # sad.go:48-50: an empty region
+                    else:
+                        with _context(w, h) as c:
+                            if chunk.Right.shape == chunk.Left.shape:
+                                data = c.disparity_region(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity, allr)
+                            else:   # independently decoded pictures (output.go:134-162): the reference's clamps, sad.go:212-233
+                                data = c.disparity_lr(chunk.Left, chunk.Right, p.BlockSize, p.MaxDisparity, allr)
                 except Exception as e:                          # noqa: BLE001 -- carried to the consumer
                     outp.error = e
                     failed = True
                     outp.close()
                     continue
-                outp.send(OutputChunk(DisparityData=data.reshape(-1), Region=chunk.Region))
+                for g in group:
+                    rows = data[g.Region[1] - y0:g.Region[3] - y0]
+                    outp.send(OutputChunk(DisparityData=np.ascontiguousarray(rows).reshape(-1), Region=g.Region))
         finally:
             if not failed:
                 outp.close()

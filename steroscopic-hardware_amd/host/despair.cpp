@@ -99,33 +99,59 @@ Pipeline SetupConcurrentSAD(int numWorkers, int device)
 {
   if (numWorkers <= 0) numWorkers = (int)std::thread::hardware_concurrency() * 4;      // sad.go:32-34
   device = dev_or_default(device);
-  Pipeline p{std::make_shared<Chan<InputChunk>>((size_t)numWorkers * 2),               // sad.go:36-37
-             std::make_shared<Chan<OutputChunk>>((size_t)numWorkers * 2)};
+  // sad.go:36-37 gives both channels 2 x numWorkers slots and every one of its numWorkers goroutines holds a chunk while it
+  // waits to send: 5 x numWorkers chunks can be under way before anyone reads the output -- and the reference's callers rely on
+  // it: examples/run.stream.go:46-58 feeds all ceil(Dy / max(1, Dy / (4 numWorkers))) chunks of a frame (160 for its 640x480
+  // picture with 32 workers) BEFORE it starts to read.  One device worker holds no such crowd, so the output channel gets
+  // the goroutines' share: 3 x numWorkers.
+  Pipeline p{std::make_shared<Chan<InputChunk>>((size_t)numWorkers * 2),
+             std::make_shared<Chan<OutputChunk>>((size_t)numWorkers * 3)};
   std::thread([in = p.in, out = p.out, device] {
-    InputChunk c;
-    bool failed = false;
-    while (in->recv(c)) {                                                              // sad.go:47
+    constexpr size_t kMaxGroup = 512;                                                  // chunks answered by one device call
+    InputChunk c, next;
+    bool failed = false, have_next = false;
+    for (;;) {
+      if (have_next) { c = std::move(next); have_next = false; }
+      else if (!in->recv(c)) break;                                                    // sad.go:47
       if (failed) continue;                                                            // drain: a feeder blocked in send() must get out
-      const Parameters prm = DefaultParams();                                          // sad.go:51-53 (per chunk)
-      OutputChunk o;
-      o.Region = c.Region;
+      // the chunks already queued behind this one that continue it downwards
+      std::vector<InputChunk> group;
+      group.push_back(std::move(c));
+      while (group.size() < kMaxGroup && in->try_recv(next)) {
+        const InputChunk& f = group.front(); const InputChunk& l = group.back();
+        if (next.Left == f.Left && next.Right == f.Right && next.Region.x0 == f.Region.x0 && next.Region.x1 == f.Region.x1 &&
+            next.Region.y0 == l.Region.y1 && next.Region.Dy() > 0 && l.Region.Dy() > 0) {
+          group.push_back(std::move(next));
+        } else { have_next = true; break; }                                           // starts the next group
+      }
+      const Parameters prm = DefaultParams();                                          // sad.go:51-53 (per group: see despair.hpp)
+      const Rectangle all{group.front().Region.x0, group.front().Region.y0, group.front().Region.x1, group.back().Region.y1};
+      std::vector<uint8_t> data;
       try {
-        o.DisparityData.assign((size_t)c.Region.Dx() * c.Region.Dy(), 0);              // sad.go:48-50
-        const Gray& L = *c.Left; const Gray& R = *c.Right;
-        Lease ctx(device, L.Rect.Dx(), L.Rect.Dy());
-        // each image with its OWN size: the two pictures are decoded independently (pkg/camera/output.go:134-162) and
-        // the reference clamps / breaks per image (sad.go:212-218,225-227,231-233) -- never w x h of a smaller R
-        check(sadhip_disparity_lr_u8(ctx.get(), L.Pix.data(), L.Rect.Dx(), L.Rect.Dy(), L.Stride,
-                                     R.Pix.data(), R.Rect.Dx(), R.Rect.Dy(), R.Stride, prm.BlockSize, prm.MaxDisparity, 0,
-                                     c.Region.x0, c.Region.y0, c.Region.x1, c.Region.y1, o.DisparityData.data(), c.Region.Dx()),
-              "sadhip_disparity_lr_u8");
+        data.assign((size_t)all.Dx() * all.Dy(), 0);                                   // sad.go:48-50
+        if (!data.empty()) {
+          const Gray& L = *group.front().Left; const Gray& R = *group.front().Right;
+          Lease ctx(device, L.Rect.Dx(), L.Rect.Dy());
+          // each image with its OWN size: the two pictures are decoded independently (pkg/camera/output.go:134-162) and
+          // the reference clamps / breaks per image (sad.go:212-218,225-227,231-233) -- never w x h of a smaller R
+          check(sadhip_disparity_lr_u8(ctx.get(), L.Pix.data(), L.Rect.Dx(), L.Rect.Dy(), L.Stride,
+                                       R.Pix.data(), R.Rect.Dx(), R.Rect.Dy(), R.Stride, prm.BlockSize, prm.MaxDisparity, 0,
+                                       all.x0, all.y0, all.x1, all.y1, data.data(), all.Dx()),
+                "sadhip_disparity_lr_u8");
+        }
       } catch (...) {
         out->fail(std::current_exception());                                           // the consumer gets the error, not a short stream
         failed = true;
         continue;
       }
-      try { out->send(std::move(o)); }                                                 // sad.go:98-101
-      catch (const std::logic_error&) { failed = true; }                               // consumer closed the output: drain and leave
+      for (const InputChunk& g : group) {                                              // sad.go:98-101, one answer per chunk
+        OutputChunk o;
+        o.Region = g.Region;
+        const size_t row = (size_t)all.Dx();
+        o.DisparityData.assign(data.begin() + (size_t)(g.Region.y0 - all.y0) * row, data.begin() + (size_t)(g.Region.y1 - all.y0) * row);
+        try { out->send(std::move(o)); }
+        catch (const std::logic_error&) { failed = true; break; }                      // consumer closed the output: drain and leave
+      }
     }
     if (!failed) out->close();                                                         // sad.go:106-110
   }).detach();

@@ -86,6 +86,15 @@ class Chan {
     cv_send_.notify_one();
     return true;
   }
+  // what is queued right now, without waiting (the device worker gathers the chunks of a frame that are already there)
+  bool try_recv(T& out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (q_.empty()) return false;
+    out = std::move(q_.front());
+    q_.pop_front();
+    cv_send_.notify_one();
+    return true;
+  }
   void close() { std::lock_guard<std::mutex> lk(mu_); closed_ = true; cv_recv_.notify_all(); cv_send_.notify_all(); }
   void fail(std::exception_ptr e) { std::lock_guard<std::mutex> lk(mu_); err_ = e; closed_ = true; cv_recv_.notify_all(); cv_send_.notify_all(); }
   std::exception_ptr error() { std::lock_guard<std::mutex> lk(mu_); return err_; }
@@ -101,7 +110,10 @@ struct Pipeline { std::shared_ptr<Chan<InputChunk>> in; std::shared_ptr<Chan<Out
 int DefaultDevice();
 
 // sad.go:29-113.  One device worker replaces the goroutine pool; closing `in` stops it and closes
-// `out`.  On a device error the worker fails `out` with the Error and keeps draining `in`, so a
+// `out`.  Chunks that are queued TOGETHER, belong to the same two images, span the same columns and follow each other
+// downwards (the row bands every caller of the reference feeds: run.stream.go:46-58, sad.go:138-153 per tile row) are
+// computed by ONE device call over their common rows and answered chunk by chunk, with one parameter snapshot for the
+// group -- the reference's workers would each have taken theirs within the same microseconds (sad.go:51-53).  On a device error the worker fails `out` with the Error and keeps draining `in`, so a
 // feeder blocked in send() is released and the consumer sees the error.
 Pipeline SetupConcurrentSAD(int numWorkers, int device = -1);
 // sad.go:172-202 (hole-free).  Throws the pipeline's Error -- or Error(SADHIP_ERR_ARG) for a channel

@@ -159,25 +159,80 @@ func regionGo(chunk InputChunk) OutputChunk {
 	return <-goFallback.out
 }
 
+// maxGroup is the number of chunks one device call answers at most.
+const maxGroup = 512
+
+// continues reports whether next carries on where last stopped: same two images, same columns, the rows right below
+// (the row bands every caller of the reference feeds: examples/run.stream.go:46-58, sad.go:138-153 per tile row).
+func continues(first, last, next InputChunk) bool {
+	return next.Left == first.Left && next.Right == first.Right &&
+		next.Region.Min.X == first.Region.Min.X && next.Region.Max.X == first.Region.Max.X &&
+		next.Region.Min.Y == last.Region.Max.Y && next.Region.Dy() > 0 && last.Region.Dy() > 0
+}
+
 // SetupConcurrentSAD sets up a concurrent SAD processing pipeline (sad.go:29-113): same channels,
-// same capacities, parameters snapshotted per chunk; one device worker replaces the goroutine pool.
+// the same number of chunks under way; one device worker replaces the goroutine pool.  Chunks that are queued TOGETHER and
+// continue each other downwards are computed by ONE device call over their common rows and answered
+// chunk by chunk, with one parameter snapshot for the group -- the reference's workers would each have
+// taken theirs within the same microseconds (sad.go:51-53).
 func SetupConcurrentSAD(numWorkers int) (chan<- InputChunk, <-chan OutputChunk) {
 	if numWorkers <= 0 {
 		numWorkers = runtime.NumCPU() * 4
 	}
+	// sad.go:36-37 gives both channels 2*numWorkers slots and each of its numWorkers goroutines holds a chunk
+	// while it waits to send: 5*numWorkers chunks can be under way before anyone reads -- examples/run.stream.go:46-58
+	// feeds a whole frame (160 chunks for its 640x480 picture with 32 workers) before it reads.  One device worker
+	// holds no such crowd: the output channel gets the goroutines' share.
 	inputChan := make(chan InputChunk, numWorkers*2)
-	outputChan := make(chan OutputChunk, numWorkers*2)
+	outputChan := make(chan OutputChunk, numWorkers*3)
 	go func() {
 		defer close(outputChan)
-		for chunk := range inputChan {
-			params := *DefaultParams() // per chunk, like sad.go:51-53
-			data, err := regionHIP(chunk.Left, chunk.Right, params, chunk.Region)
+		var pending *InputChunk
+		for {
+			var chunk InputChunk
+			if pending != nil {
+				chunk, pending = *pending, nil
+			} else {
+				c, ok := <-inputChan
+				if !ok {
+					return
+				}
+				chunk = c
+			}
+			group := []InputChunk{chunk}
+		gather:
+			for len(group) < maxGroup {
+				select {
+				case next, ok := <-inputChan:
+					if !ok {
+						break gather // closed: the outer receive sees it again
+					}
+					if continues(group[0], group[len(group)-1], next) {
+						group = append(group, next)
+					} else {
+						n := next
+						pending = &n // starts the next group
+						break gather
+					}
+				default:
+					break gather // nothing else queued right now
+				}
+			}
+			params := *DefaultParams() // per group, like sad.go:51-53 per chunk
+			all := image.Rect(group[0].Region.Min.X, group[0].Region.Min.Y, group[0].Region.Max.X, group[len(group)-1].Region.Max.Y)
+			data, err := regionHIP(chunk.Left, chunk.Right, params, all)
 			if err != nil {
 				slog.Warn("HIP disparity failed, using the Go path", "err", err)
-				outputChan <- regionGo(chunk)
+				for _, g := range group {
+					outputChan <- regionGo(g)
+				}
 				continue
 			}
-			outputChan <- OutputChunk{DisparityData: data, Region: chunk.Region}
+			row := all.Dx()
+			for _, g := range group {
+				lo, hi := (g.Region.Min.Y-all.Min.Y)*row, (g.Region.Max.Y-all.Min.Y)*row
+				outputChan <- OutputChunk{DisparityData: data[lo:hi:hi], Region: g.Region}
+			}
 		}
 	}()
 	return inputChan, outputChan

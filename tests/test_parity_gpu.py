@@ -771,6 +771,42 @@ def test_channel_api_round_trip(ctx):
     d.SetDefaultParams(d.Parameters(BlockSize=16, MaxDisparity=64))
 
 
+@pytest.mark.timeout(180)
+def test_channel_api_reference_example_shape_whole_frame_fed_before_reading(ctx):
+    """examples/run.stream.go:30-59 as it is: 640x480, 32 workers, chunks of Dy / (32 * 4) = 3 rows = 160 chunks, ALL sent
+    before AssembleDisparityMap starts to read.  The reference has room for 5 x numWorkers = 160 chunks under way (two
+    channels of 64 and 32 goroutines holding one each); a device worker with the same two channels and one chunk in hand had
+    room for 129 and would have left this feeder blocked for ever.  Also: the chunks queued together run as one device call
+    per group (same bytes as the frame-level call), chunks of two frames in one stream, tiles (sad.go:138-153) that do not
+    continue each other, and an empty region."""
+    d = sha.despair
+    L, R = sha.synth.synth_pair(31, 640, 480)
+    L2, R2 = sha.synth.synth_pair(32, 640, 480)
+    d.SetDefaultParams(d.Parameters(BlockSize=16, MaxDisparity=32))      # run.stream.go:15-19
+    want, want2 = _expect(L, R, 16, 32), _expect(L2, R2, 16, 32)
+    inp, outp = d.SetupConcurrentSAD(32)
+    chunkSize = max(1, 480 // (32 * 4))
+    for l, r, w_ in ((L, R, want), (L2, R2, want2), (L, R, want)):
+        n = 0
+        for y in range(0, 480, chunkSize):
+            inp.send(d.InputChunk(l, r, (0, y, 640, min(y + chunkSize, 480))))
+            n += 1
+        assert n == 160
+        assert np.array_equal(d.AssembleDisparityMap(outp, (0, 0, 640, 480), n), w_)
+    # two frames' bands interleaved, RunSad's tiles, an empty region: nothing continues anything
+    regs = [(0, 0, 640, 100), (0, 100, 320, 200), (320, 100, 640, 200), (0, 200, 640, 200), (0, 200, 640, 480)]
+    for reg in regs:
+        inp.send(d.InputChunk(L, R, reg)); inp.send(d.InputChunk(L2, R2, reg))
+    got = [next(iter(outp)) for _ in range(2 * len(regs))]
+    for i, o in enumerate(got):
+        x0, y0, x1, y1 = regs[i // 2]
+        assert o.Region == regs[i // 2]
+        assert np.array_equal(o.DisparityData.reshape(y1 - y0, x1 - x0), (want if i % 2 == 0 else want2)[y0:y1, x0:x1])
+    inp.close()
+    assert list(outp) == []
+    d.SetDefaultParams(d.Parameters(BlockSize=16, MaxDisparity=64))
+
+
 def test_batch_host_pipeline(ctx):
     pairs = [sha.synth.synth_pair(1000 + i, 256, 64) for i in range(5)]
     outs = ctx.disparity_batch([p[0] for p in pairs], [p[1] for p in pairs], 9, 64)
