@@ -586,10 +586,13 @@ def main():
             "gpu_output_matches": ok}
         if not ok:
             res["parity_error"] = "a GPU frame differs from the CPU oracle"
-    print(json.dumps(res))
+    print(json.dumps(res), flush=True)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if "parity_error" in res:                                     # a wrong kernel or a differing frame fails the RUN, not just a JSON key
+        print(f"bench.py: parity_error: {res['parity_error']}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

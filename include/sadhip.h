@@ -44,12 +44,15 @@
 extern "C" {
 #endif
 
-#define SADHIP_ABI_VERSION 4   /* 2: flag validation, MIRROR_VERILOG, sadhip_last_kernel_kind, sadhip_pool_*;
+#define SADHIP_ABI_VERSION 5   /* 2: flag validation, MIRROR_VERILOG, sadhip_last_kernel_kind, sadhip_pool_*;
                                 * 3: sadhip_disparity_lr_u8 (left / right images of different sizes), sadhip_host_* (page-locked
                                 *    host memory), sadhip_plan_describe_batch;
                                 * 4: sadhip_pool_describe / sadhip_device_describe / sadhip_pool_host_alloc (NUMA placement), sadhip_host_register
                                 *    refuses overlapping ranges, the generic kernel's work bound (SADHIP_GENERIC_MAX_WORK),
-                                *    "nwh" in the plan lines */
+                                *    "nwh" in the plan lines;
+                                * 5: sadhip_host_register accepts whole pages of a mapping of the caller's own only (never the program
+                                *    break or a stack), sadhip_ctx_set_copy_spin_us / _get_copy_spin_us / sadhip_pool_set_copy_spin_us,
+                                *    SADHIP_FLAG_HOST_GRAY for sadhip_disparity_rgba_u8 */
 
 #if defined(__GNUC__)
 #define SADHIP_API __attribute__((visibility("default")))
@@ -104,6 +107,14 @@ extern "C" {
                                         * committed golden files; fixtures regenerated with it describe the intended
                                         * sliding-window search the RTL is being brought up against. */
 
+#define SADHIP_FLAG_HOST_GRAY 32u  /* sadhip_disparity_rgba_u8 ONLY (SADHIP_ERR_ARG elsewhere; ABI 5): the host threads that stage the two
+                                    * decoded pictures into page-locked memory write LUMINANCE rows instead of copies of the pictures
+                                    * -- the same integer formula as the device kernel, bit for bit (gray.go:52-55 on
+                                    * color.NRGBA.RGBA()) -- so a quarter of the bytes cross the bus (1080p RGBA pair: 16.6 MB ->
+                                    * 4.1 MB).  For callers whose pictures are in ordinary (pageable) memory and whose
+                                    * cores are free; without the flag the pictures are uploaded as they are and converted on
+                                    * the device (the default; the better choice for pictures in sadhip_host_alloc memory). */
+
 typedef struct sadhip_ctx sadhip_ctx;   /* opaque per-device context */
 
 /* ---- library / device queries ------------------------------------------------------------ */
@@ -131,6 +142,15 @@ SADHIP_API int sadhip_ctx_device(const sadhip_ctx* ctx, int* device);
 #define SADHIP_DEFAULT_COPY_THREADS 6
 SADHIP_API int sadhip_ctx_set_copy_threads(sadhip_ctx* ctx, int n);
 SADHIP_API int sadhip_ctx_get_copy_threads(sadhip_ctx* ctx, int* n);
+/* How long such a thread (and the caller waiting for them) polls for the next piece of work before it sleeps on a condition
+ * variable (ABI 5): us = 0..SADHIP_MAX_COPY_SPIN_US microseconds, default SADHIP_DEFAULT_COPY_SPIN_US.  The pieces of one call
+ * -- left plane, right plane, result -- follow each other within that time, and waking a sleeping core costs 20-50 us per piece
+ * (1080p, one call: 0 = +0.03..0.06 ms).  A host that calls once a second and wants no polling at all in its process (the
+ * WebUI's OutputCamera) sets 0: the threads then sleep as soon as they have no work.  Takes effect at once. */
+#define SADHIP_DEFAULT_COPY_SPIN_US 150
+#define SADHIP_MAX_COPY_SPIN_US 10000
+SADHIP_API int sadhip_ctx_set_copy_spin_us(sadhip_ctx* ctx, int us);
+SADHIP_API int sadhip_ctx_get_copy_spin_us(sadhip_ctx* ctx, int* us);
 
 /* ---- whole frame, host buffers (synchronous) ------------------------------------------------
  * Replaces RunSad (sad.go:119-169) and the OutputCamera frame loop
@@ -277,13 +297,19 @@ SADHIP_API int sadhip_plan_describe_batch(int w, int h, int block, int maxdisp, 
  * ranges and then uses asynchronous linear copies; results are identical either way.  Free / unregister a
  * range only when no call that was given pointers into it is still running (every entry point has finished
  * with the caller's memory when it returns).
- * Prefer sadhip_host_alloc where the host can choose its frame memory: sadhip_host_register (hipHostRegister) locks the
- * CALLER's pages in place -- the mechanism the withdrawn pageable path relied on per call; a registration
- * is long-lived and made once, the way that mechanism is normally used, and has shown no fault here, but its memory must stay
- * mapped and untouched by free() / munmap() / realloc() until sadhip_host_unregister.
+ * Prefer sadhip_host_alloc where the host can choose its frame memory.  sadhip_host_register (hipHostRegister) locks the
+ * CALLER's pages in place -- the mechanism the withdrawn pageable path relied on per call -- and is
+ * therefore limited to memory no allocator shares or recycles (ABI 5).  CONTRACT, checked at the call against /proc/self/maps:
+ *   - p is 4 KiB-aligned and bytes is a multiple of 4096: whole pages, so that no byte of another object shares a locked page;
+ *   - every page is mapped readable + writable by a mapping of the caller's own (mmap: anonymous, shared memory, a driver's
+ *     capture buffers); memory inside the program break ("[heap]": malloc's main arena returns pages to the system and takes
+ *     them back under the caller) or a stack is refused -- as is anything that cannot be verified;
+ *   - NOT checked, the caller's duty: the mapping stays mapped, at this address, until sadhip_host_unregister returns -- no
+ *     munmap / mremap / madvise(MADV_DONTNEED / MADV_FREE) of any part of it, and no free() if it came from an allocator's
+ *     own mmap (a large malloc / posix_memalign block is such a mapping only as long as the allocator says so: do not rely on it).
+ *   Anything else returns SADHIP_ERR_ARG and registers nothing; sadhip_last_error() says which rule.
  * The known ranges are DISJOINT page by page: sadhip_host_register of memory that shares a 4 KiB page with a sadhip_host_alloc
- * block or an earlier registration (a sub-range, a super-range, a partial overlap, a neighbour that starts or ends inside the
- * same page) returns SADHIP_ERR_ARG and registers nothing. */
+ * block or an earlier registration (a sub-range, a super-range, a partial overlap) returns SADHIP_ERR_ARG and registers nothing. */
 SADHIP_API int sadhip_host_alloc(size_t bytes, void** out);
 SADHIP_API int sadhip_host_free(void* p);
 SADHIP_API int sadhip_host_register(void* p, size_t bytes);
@@ -300,8 +326,13 @@ typedef struct sadhip_pool sadhip_pool;
 SADHIP_API int sadhip_pool_create(const int* devices, int n_devices, int max_w, int max_h, sadhip_pool** out);
 SADHIP_API int sadhip_pool_destroy(sadhip_pool* pool);
 SADHIP_API int sadhip_pool_size(const sadhip_pool* pool, int* n_devices);
-/* sadhip_ctx_set_copy_threads for every entry's context (n per entry, 1..32): eight devices at the default are 48 host threads. */
+/* sadhip_ctx_set_copy_threads for every entry's context (n per entry, 1..32).  A pool of G devices runs G worker threads (one
+ * per entry, each inside its device's calls) and, once an entry has seen a frame that is not in page-locked memory, n - 1 copy
+ * helpers under it: eight devices at the default are 8 + 40 = 48 host threads; frames from sadhip_host_alloc /
+ * sadhip_pool_host_alloc never start the helpers. */
 SADHIP_API int sadhip_pool_set_copy_threads(sadhip_pool* pool, int n);
+/* sadhip_ctx_set_copy_spin_us for every entry's context (ABI 5). */
+SADHIP_API int sadhip_pool_set_copy_spin_us(sadhip_pool* pool, int us);
 SADHIP_API int sadhip_pool_batch_u8(sadhip_pool* pool, int n,
                          const uint8_t* const* lefts, const uint8_t* const* rights,
                          int w, int h, int lstride, int rstride,

@@ -24,9 +24,10 @@ FLAG_FORCE_GENERIC = 2
 FLAG_MIRROR_SADC = 4
 FLAG_MIRROR_TESTPY = 8
 FLAG_MIRROR_VERILOG = 16
+FLAG_HOST_GRAY = 32           # sadhip_disparity_rgba_u8 only: the copy threads write luminance rows (a quarter of the bytes uploaded)
 KIND_GENERIC, KIND_COLWAVE, KIND_MIRROR_SADC, KIND_MIRROR_TESTPY, KIND_MIRROR_VERILOG, KIND_GENERIC_SLIDING = range(6)
 GENERIC_MAX_WORK = 65536
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_BLOCK = 255
 MAX_MAXDISP = 4096
 
@@ -44,6 +45,8 @@ SYMBOLS = {
     "sadhip_ctx_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "sadhip_ctx_set_copy_threads": (C.c_int, [C.c_void_p, C.c_int]),
     "sadhip_ctx_get_copy_threads": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "sadhip_ctx_set_copy_spin_us": (C.c_int, [C.c_void_p, C.c_int]),
+    "sadhip_ctx_get_copy_spin_us": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "sadhip_disparity_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int]),
     "sadhip_disparity_region_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -74,6 +77,7 @@ SYMBOLS = {
     "sadhip_pool_destroy": (C.c_int, [C.c_void_p]),
     "sadhip_pool_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "sadhip_pool_set_copy_threads": (C.c_int, [C.c_void_p, C.c_int]),
+    "sadhip_pool_set_copy_spin_us": (C.c_int, [C.c_void_p, C.c_int]),
     "sadhip_pool_batch_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
                                        C.POINTER(C.c_void_p), C.c_int]),
@@ -243,14 +247,35 @@ class HostBuffer:
             pass
 
 
-def host_register(a):
-    """Page-locks the memory of a C-contiguous numpy array (sadhip_host_register); pair with host_unregister."""
-    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
-    _check(lib().sadhip_host_register(a.ctypes.data, a.nbytes))
+class MappedBuffer:
+    """Memory the CALLER owns, page-locked in place (sadhip_host_register): an anonymous mmap of whole 4 KiB pages -- the only
+    kind of memory a registration accepts (ABI 5: page-aligned whole pages of a mapping of the caller's own, never the
+    program break; include/sadhip.h has the contract).  ``.array`` / ``.view(shape)`` like HostBuffer; close() unregisters
+    first and unmaps afterwards."""
 
+    def __init__(self, nbytes):
+        import mmap
+        self.nbytes = (int(nbytes) + 4095) // 4096 * 4096
+        self._map = mmap.mmap(-1, self.nbytes)
+        self.array = np.frombuffer(self._map, dtype=np.uint8)
+        self._registered = False
+        _check(lib().sadhip_host_register(self.array.ctypes.data, self.nbytes))
+        self._registered = True
 
-def host_unregister(a):
-    _check(lib().sadhip_host_unregister(a.ctypes.data))
+    def view(self, shape):
+        return self.array[:int(np.prod(shape))].reshape(shape)
+
+    def close(self):
+        if self._registered:
+            self._registered = False
+            _check(lib().sadhip_host_unregister(self.array.ctypes.data))
+        self.array = None                                     # (the mapping is released when the last view of it is)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def _img(a, name):
@@ -292,6 +317,15 @@ class Context:
     def copy_threads(self):
         n = C.c_int(0)
         _check(lib().sadhip_ctx_get_copy_threads(self._h, C.byref(n)))
+        return n.value
+
+    def set_copy_spin_us(self, us):
+        """How long a copy thread polls for its next piece before it sleeps: 0..10000 us (0 = sleep at once)."""
+        _check(lib().sadhip_ctx_set_copy_spin_us(self._h, int(us)))
+
+    def copy_spin_us(self):
+        n = C.c_int(0)
+        _check(lib().sadhip_ctx_get_copy_spin_us(self._h, C.byref(n)))
         return n.value
 
     def disparity(self, left, right, block, maxdisp, flags=0, out=None):
@@ -471,6 +505,9 @@ class Pool:
     def set_copy_threads(self, n):
         """Host threads per entry (its worker included) that stage frames which are not in page-locked memory: 1..32."""
         _check(lib().sadhip_pool_set_copy_threads(self._h, int(n)))
+
+    def set_copy_spin_us(self, us):
+        _check(lib().sadhip_pool_set_copy_spin_us(self._h, int(us)))
 
     def batch(self, lefts, rights, block, maxdisp, flags=0, outs=None):
         if len(lefts) == 0:

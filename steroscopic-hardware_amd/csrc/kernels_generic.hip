@@ -9,6 +9,7 @@
 // :205-244:
 //     dmax(x) = min(D, max(0, x - hs)),   window clipped to the image, L and R aligned.
 #include "sadhip_kernels.h"
+#include <mutex>
 
 namespace sadhip {
 
@@ -16,14 +17,52 @@ static thread_local int g_last_kind = KIND_NONE;
 void note_launch(int kind) { g_last_kind = kind; }
 int last_launch_kind() { return g_last_kind; }
 
-// ---- stream-ordered scratch (sadhip_kernels.h): the device's DEFAULT memory pool ------------------------------------
-// Round 4 tried a pool of the library's own with a 1 GiB release threshold (0.27 -> 0.015 ms per 256 MB allocation cycle,
-// tools/ubench/malloc_async.hip).  After three clean runs of the GPU suite one run aborted (SIGABRT, no message) inside a
-// later multi-pass call on another context's stream: blocks cached in such a pool stay tagged with the stream that freed
-// them, and the suite creates and destroys contexts (streams) all the time.  The default pool releases unused memory at
-// every synchronise (threshold 0) and has run this path since round 1 without a single abort; 0.25 ms per multi-pass call is
-// not worth a lifetime coupling between a process-wide cache and per-context streams.
-hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s) { return hipMallocAsync(p, bytes, s); }
+// ---- stream-ordered scratch from the library's own pool (sadhip_kernels.h) ---------------------------------------
+// The device's default pool hands unused memory back to the driver at every synchronise (release threshold 0): the 256 MB key
+// scratch of a multi-pass call then costs an allocation from the driver per call, 0.25-0.27 ms (tools/ubench/malloc_async.hip,
+// profiles/ubench_malloc_async.txt).  One pool per device with a 1 GiB release threshold keeps it: 0.015-0.027 ms.  History:
+// built in round 4, withdrawn the same round as the suspect of an abort of the GPU suite, and exonerated two runs later -- the
+// same abort came back twice without it and was a GPU memory access fault on a host page of the (then) in-place host copy path
+//  -- and put back in round 5.  The pool is process-wide and never destroyed (its blocks belong to no
+// context or stream: a block freed on a stream that is destroyed afterwards is reusable once that stream's work has finished,
+// which the runtime's stream-ordered allocator tracks by events, not by the stream object).
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_pool_mu;
+hipMemPool_t g_pools[kMaxDevices] = {};
+bool g_pool_tried[kMaxDevices] = {};
+
+hipMemPool_t scratch_pool()
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (!g_pool_tried[dev]) {
+    g_pool_tried[dev] = true;
+    hipMemPoolProps props{};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
+      unsigned long long keep = 1ull << 30;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      g_pools[dev] = pool;
+    } else {
+      (void)hipGetLastError();                               // no pool: the device's default one serves (correct, slower)
+    }
+  }
+  return g_pools[dev];
+}
+}  // namespace
+
+hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s)
+{
+  if (hipMemPool_t pool = scratch_pool()) return hipMallocFromPoolAsync(p, bytes, pool, s);
+  return hipMallocAsync(p, bytes, s);
+}
+
 hipError_t scratch_free(void* p, hipStream_t s) { return hipFreeAsync(p, s); }
 
 __global__ void __launch_bounds__(256)

@@ -167,12 +167,52 @@ extern "C" int sadhip_host_free(void* p)
   return SADHIP_OK;
 }
 
+// What sadhip_host_register accepts (ABI 5).  hipHostRegister locks the CALLER's pages in place; the round-4 memory access
+// faults happened on caller pages the runtime had locked in place, and both mechanisms the record admits
+// -- a lock that outlives the memory it was taken on (the heap returns pages to the system and takes them back: brk / trim),
+// or an access past the locked extent into a neighbouring heap object's page -- need the locked pages to be SHARED with, or
+// recycled by, an allocator.  So a registration is whole pages of a mapping of the caller's own: 4 KiB-aligned start, a
+// multiple of 4 KiB long, every page mapped readable + writable, and no part of it inside the program break ("[heap]": malloc's
+// main arena, which grows and shrinks under the caller) or a stack.  Checked against /proc/self/maps; anything that cannot be
+// verified is refused.  why: a sentence for sadhip_last_error().
+static bool registrable(const void* p, size_t bytes, char* why, size_t cap)
+{
+  constexpr uintptr_t PG = 4096;
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  if ((lo & (PG - 1)) || (bytes & (PG - 1))) {
+    snprintf(why, cap, "[%p, +%zu) is not whole 4 KiB pages (page-aligned start, length a multiple of 4096)", p, bytes);
+    return false;
+  }
+  FILE* f = fopen("/proc/self/maps", "r");
+  if (!f) { snprintf(why, cap, "/proc/self/maps is not readable: the mapping behind %p cannot be verified", p); return false; }
+  char line[512];
+  uintptr_t covered = lo;                                      // [lo, covered) lies in acceptable mappings so far
+  bool ok = true;
+  while (ok && covered < hi && fgets(line, sizeof(line), f)) {
+    unsigned long a = 0, b = 0; char perms[8] = ""; int name_at = 0;
+    if (sscanf(line, "%lx-%lx %7s %*s %*s %*s %n", &a, &b, perms, &name_at) < 3) continue;
+    if (b <= covered) continue;                                // (maps are sorted by address)
+    if (a > covered) break;                                    // a hole at `covered`
+    const char* name = name_at > 0 ? line + name_at : "";
+    if (perms[0] != 'r' || perms[1] != 'w') { snprintf(why, cap, "page %p of the range is not mapped readable and writable (%s)", (void*)covered, perms); ok = false; }
+    else if (!strncmp(name, "[heap]", 6) || !strncmp(name, "[stack", 6)) {
+      snprintf(why, cap, "[%p, +%zu) lies in %.7s: memory of an allocator that returns and re-takes pages under the caller cannot be page-locked in place -- use sadhip_host_alloc, or register a mapping of your own (mmap)", p, bytes, name);
+      ok = false;
+    }
+    else covered = b;
+  }
+  fclose(f);
+  if (ok && covered < hi) { snprintf(why, cap, "page %p of the range is not mapped", (void*)covered); ok = false; }
+  return ok;
+}
+
 extern "C" int sadhip_host_register(void* p, size_t bytes)
 {
   if (!p) return fail(SADHIP_ERR_NULL, "p is NULL");
   if (bytes == 0) return fail(SADHIP_ERR_ARG, "bytes=0");
-  // ranges are disjoint, page by page: a sub-range of a sadhip_host_alloc block (already page-locked), of an earlier
-  // registration, or a range that merely shares a 4 KiB page with one is refused
+  char why[400];
+  if (!registrable(p, bytes, why, sizeof(why))) return fail(SADHIP_ERR_ARG, "%s", why);
+  // ranges are disjoint: a sub-range of a sadhip_host_alloc block (already page-locked) or of an earlier registration is refused
   if (pin_overlaps(p, bytes)) return fail(SADHIP_ERR_ARG, "[%p, +%zu) shares a page with page-locked memory this library already knows", p, bytes);
   const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
   if (e != hipSuccess) {
@@ -255,7 +295,8 @@ struct sadhip_ctx {
   // handed pageable caller memory to hipMemcpy2DAsync (the runtime locks the caller's pages in place: 0.14 ms instead of
   // 0.28 ms for the two uploads of a 1080p pair, tools/ubench/h2d_paths.hip); round 4 saw that path end a process with
   // "Memory access fault by GPU ... on address <a host heap page>" three times in some twenty full test runs (DESIGN.md
-  // section 6b), so it survives only in the diagnostics build (-DSADHIP_TUNING, SADHIP_TUNE_HOSTCOPY=direct) for comparison.
+  // section 6b: profiles/r04_gpu_fault_{1,2}.log).  No build of the library contains that path any more (round 5); its A/B
+  // numbers are kept in profiles/r04_ab_hostcopy*.txt.
   // Every host entry point synchronises its stream before returning -- on error exits too.
   // Staged copies are split two ways (tools/ab_hostcopy.py, profiles/r04_ab_hostcopy.txt; 1080p, BlockSize 9, MaxDisparity 64):
   // across kCopyHelpers + 1 host threads (CopyGang above) -- one thread: 0.39 ms per call on a pair that is in the caches,
@@ -264,11 +305,11 @@ struct sadhip_ctx {
   // threads copy band b+1.  With the gang a band below 8 MB no longer pays (each costs a copy call and a gang hand-off:
   // sadhip_disparity_rgba_u8 0.55 ms at 8 MB, 0.63 at 2 MB): a 1080p plane or decoded picture goes in one piece, a 4K
   // RGBA picture in four.
-  bool direct_pageable = false;
   bool pair_upload = true;                     // a staged pair of a batch travels as one upload (diagnostics build: SADHIP_TUNE_PAIRUP=0)
   size_t band_bytes = (size_t)8 << 20;
   static constexpr int kCopyHelpers = SADHIP_DEFAULT_COPY_THREADS - 1;       // + the calling thread
   int copy_helpers = kCopyHelpers;
+  int copy_spin_us = CopyGang::kSpinUs;
   std::unique_ptr<CopyGang> gang;
   std::mutex mu;
 };
@@ -386,7 +427,6 @@ extern "C" int sadhip_ctx_create(int device, int max_w, int max_h, int max_batch
   c->pitch = align_up((size_t)max_w, 256);
   c->plane = c->pitch * (size_t)max_h;
 #ifdef SADHIP_TUNING
-  if (const char* e = getenv("SADHIP_TUNE_HOSTCOPY")) c->direct_pageable = strcmp(e, "direct") == 0;
   if (const char* e = getenv("SADHIP_TUNE_STREAM")) sadhip::stream_stores() = atoi(e) != 0;
   if (const char* e = getenv("SADHIP_TUNE_PAIRUP")) c->pair_upload = atoi(e) != 0;
   if (const char* e = getenv("SADHIP_TUNE_BANDKB")) c->band_bytes = (size_t)std::max(atoi(e), 4) << 10;
@@ -433,7 +473,7 @@ extern "C" int sadhip_ctx_set_copy_threads(sadhip_ctx* ctx, int n)
   if (n < 1 || n > 32) return fail(SADHIP_ERR_ARG, "copy threads n=%d (valid 1..32, the calling thread included)", n);
   std::lock_guard<std::mutex> lk(ctx->mu);                  // no call is inside a copy
   if (n - 1 == ctx->copy_helpers && ctx->gang) return SADHIP_OK;
-  CopyGang* g = new (std::nothrow) CopyGang(n - 1);
+  CopyGang* g = new (std::nothrow) CopyGang(n - 1, ctx->copy_spin_us);
   if (!g) return fail(SADHIP_ERR_NOMEM, "copy threads");
   ctx->gang.reset(g);                                       // joins the old helpers
   ctx->copy_helpers = n - 1;
@@ -445,6 +485,24 @@ extern "C" int sadhip_ctx_get_copy_threads(sadhip_ctx* ctx, int* n)
   if (!ctx || !n) return fail(SADHIP_ERR_NULL, "ctx or n is NULL");
   std::lock_guard<std::mutex> lk(ctx->mu);
   *n = ctx->copy_helpers + 1;
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_ctx_set_copy_spin_us(sadhip_ctx* ctx, int us)
+{
+  if (!ctx) return fail(SADHIP_ERR_NULL, "ctx is NULL");
+  if (us < 0 || us > SADHIP_MAX_COPY_SPIN_US) return fail(SADHIP_ERR_ARG, "copy spin us=%d (valid 0..%d)", us, SADHIP_MAX_COPY_SPIN_US);
+  std::lock_guard<std::mutex> lk(ctx->mu);                  // no call is inside a copy
+  ctx->copy_spin_us = us;
+  if (ctx->gang) ctx->gang->set_spin_us(us);
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_ctx_get_copy_spin_us(sadhip_ctx* ctx, int* us)
+{
+  if (!ctx || !us) return fail(SADHIP_ERR_NULL, "ctx or us is NULL");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *us = ctx->copy_spin_us;
   return SADHIP_OK;
 }
 
@@ -468,10 +526,11 @@ static int check_params(int w, int h, int lstride, int rstride, int block, int m
   return SADHIP_OK;
 }
 
-static int check_flags(unsigned flags)
+// extra: flag bits only the calling entry point knows (SADHIP_FLAG_HOST_GRAY: sadhip_disparity_rgba_u8)
+static int check_flags(unsigned flags, unsigned extra = 0)
 {
   const unsigned mirrors = SADHIP_FLAG_MIRROR_SADC | SADHIP_FLAG_MIRROR_TESTPY | SADHIP_FLAG_MIRROR_VERILOG;
-  const unsigned known = SADHIP_FLAG_RAW | SADHIP_FLAG_FORCE_GENERIC | mirrors;
+  const unsigned known = SADHIP_FLAG_RAW | SADHIP_FLAG_FORCE_GENERIC | mirrors | extra;
   if (flags & ~known) return fail(SADHIP_ERR_ARG, "unknown flag bits 0x%x", flags & ~known);
   const unsigned m = flags & mirrors;
   if (m & (m - 1)) return fail(SADHIP_ERR_ARG, "flags 0x%x select more than one hardware-mirror mode", flags);
@@ -581,7 +640,8 @@ static int upload_staged(sadhip_ctx* c, hipStream_t st, uint8_t* dev, uint8_t* s
 static void route_output(sadhip_ctx* c, Slot& s, uint8_t* out, int ostride, int wbytes, int rows)
 {
   s.out = out; s.ostride = ostride;
-  s.out_direct = c->direct_pageable || is_pinned(out, (size_t)(rows - 1) * ostride + wbytes);
+  (void)c;
+  s.out_direct = is_pinned(out, (size_t)(rows - 1) * ostride + wbytes);
 }
 
 static int enqueue_download(sadhip_ctx* c, Slot& s, int w, int x0, int x1, int rows);
@@ -610,10 +670,6 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
     dl = (size_t)lstride; dr = (size_t)rstride;
     HIPTRY(hipMemcpyAsync(s.dL, left + (size_t)band0 * lstride, lbytes, hipMemcpyHostToDevice, s.up));
     if (rbytes) HIPTRY(hipMemcpyAsync(s.dR, right + (size_t)band0 * rstride, rbytes, hipMemcpyHostToDevice, s.up));
-  } else if (c->direct_pageable) {                         // diagnostics build only: the runtime locks the caller's pages
-    HIPTRY(hipMemcpy2DAsync(s.dL, pitch, left + (size_t)band0 * lstride, lstride, w, band1 - band0, hipMemcpyHostToDevice, s.up));
-    if (rband1 > band0)
-      HIPTRY(hipMemcpy2DAsync(s.dR, pitch, right + (size_t)band0 * rstride, rstride, rw, rband1 - band0, hipMemcpyHostToDevice, s.up));
   } else {
     if (int st = ensure_stage(c, s)) return st;
     const int lrows = band1 - band0, rrows = rband1 - band0;
@@ -920,8 +976,9 @@ extern "C" int sadhip_disparity_batch_u8(sadhip_ctx* ctx, int n,
   if (seq) {
     for (int i = 0; i < n; ++i) {
       route_output(ctx, ctx->slot[0], outs[i], ostride, w, h);
-      if (int st = enqueue_frame(ctx, ctx->slot[0], lefts[i], rights[i], w, h, lstride, rstride, block, maxdisp, flags, 0, 0, w, h, 0, h)) return st;
-      if (int st = finish_frame(ctx, ctx->slot[0], w, 0, 0, w, h, &kms)) return st;
+      int st = enqueue_frame(ctx, ctx->slot[0], lefts[i], rights[i], w, h, lstride, rstride, block, maxdisp, flags, 0, 0, w, h, 0, h);
+      if (st == SADHIP_OK) st = finish_frame(ctx, ctx->slot[0], w, 0, 0, w, h, &kms);
+      if (st != SADHIP_OK) { (void)hipStreamSynchronize(ctx->slot[0].stream); return st; }      // nothing of the caller's stays in flight
     }
     ctx->last_kernel_ms = kms;
     ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
@@ -1085,10 +1142,6 @@ static int upload_pix(sadhip_ctx* c, hipStream_t st, uint8_t* dev, size_t cap, u
     return SADHIP_OK;
   }
   *dstride = prow;
-  if (c->direct_pageable) {                                  // diagnostics build only
-    HIPTRY(hipMemcpy2DAsync(dev, prow, pix, (size_t)stride, wbytes, h, hipMemcpyHostToDevice, st));
-    return SADHIP_OK;
-  }
   return upload_staged(c, st, dev, stage, prow, pix, (size_t)stride, wbytes, 0, h);
 }
 
@@ -1110,7 +1163,7 @@ extern "C" int sadhip_gray_u8(sadhip_ctx* ctx, const uint8_t* pix, int channels,
     size_t dstride = 0;
     if (int st = upload_pix(ctx, s, ds, pcap, hs, prow, pix, channels, w, h, stride, &dstride)) return st;
     HIPTRY(launch_gray(ds, channels, w, h, (int)dstride, ds + pcap, (int)grow, s));
-    if (ctx->direct_pageable || is_pinned(gray, (size_t)(h - 1) * gstride + w)) {
+    if (is_pinned(gray, (size_t)(h - 1) * gstride + w)) {
       HIPTRY(hipMemcpy2DAsync(gray, (size_t)gstride, ds + pcap, grow, (size_t)w, h, hipMemcpyDeviceToHost, s));
       HIPTRY(hipStreamSynchronize(s));
       return SADHIP_OK;
@@ -1134,12 +1187,50 @@ extern "C" int sadhip_disparity_rgba_u8(sadhip_ctx* ctx,
   if (int st = check_pix(left_pix, channels, w, h, lstride)) return st;
   if (int st = check_pix(right_pix, channels, w, h, rstride)) return st;
   if (int st = check_params(w, h, w, w, block, maxdisp)) return st;
-  if (int st = check_flags(flags)) return st;
+  if (int st = check_flags(flags, SADHIP_FLAG_HOST_GRAY)) return st;
   if (ostride < w) return fail(SADHIP_ERR_STRIDE, "ostride=%d w=%d", ostride, w);
   if (w > ctx->max_w || h > ctx->max_h) return fail(SADHIP_ERR_DIMS, "%dx%d exceeds context capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPTRY(hipSetDevice(ctx->device));
   const auto t0 = clk::now();
+  if (flags & SADHIP_FLAG_HOST_GRAY) {
+    // The caller's choice (SURVEY 8 f-1 "offer both"): the copy threads, which read every byte of the pictures anyway, write
+    // LUMINANCE rows into the slot's page-locked planes (host/gray_rows.h: the same integer formula as k_gray, bit for bit)
+    // instead of copies of the pictures -- a quarter of the bytes staged and sent over the bus (1080p RGBA pair: 16.6 MB ->
+    // 4.1 MB).  From there on the call is sadhip_disparity_u8's: the left plane's transfer overlaps the right picture's conversion.
+    Slot& s = ctx->slot[0];
+    float kms = 0.f;
+    const unsigned kflags = flags & ~SADHIP_FLAG_HOST_GRAY;
+    route_output(ctx, s, out, ostride, w, h);
+    const int st = synced_on_error(s.stream, [&]() -> int {
+      if (int e = ensure_stage(ctx, s)) return e;
+      const size_t pitch = pitch_for(w);
+      const uint8_t* pix[2] = {left_pix, right_pix};
+      const int strides[2] = {lstride, rstride};
+      uint8_t* host[2] = {s.hL, s.hR};
+      uint8_t* dev[2] = {s.dL, s.dR};
+      for (int k = 0; k < 2; ++k) {
+        copy_rows(ctx, RowCopy{host[k], pitch, pix[k], (size_t)strides[k], (size_t)w * channels, false, channels, w}, h);
+        HIPTRY(hipMemcpyAsync(dev[k], host[k], (size_t)(h - 1) * pitch + w, hipMemcpyHostToDevice, s.stream));
+      }
+      Job j{};
+      j.left = s.dL; j.right = s.dR; j.out = s.dO;
+      j.left_frame_stride = j.right_frame_stride = j.out_frame_stride = ctx->plane;
+      j.lstride = j.rstride = j.ostride = (int)pitch;
+      j.n = 1; j.w = w; j.h = h; j.block = block; j.maxdisp = maxdisp;
+      j.x0 = 0; j.y0 = 0; j.x1 = w; j.y1 = h; j.ox = 0; j.oy = 0;
+      j.raw = (kflags & SADHIP_FLAG_RAW) ? 1 : 0; j.row0 = 0;
+      HIPTRY(hipEventRecord(s.k0, s.stream));
+      HIPTRY(dispatch(j, kflags, s.stream));
+      HIPTRY(hipEventRecord(s.k1, s.stream));
+      if (int e = enqueue_download(ctx, s, w, 0, w, h)) return e;
+      return finish_frame(ctx, s, w, 0, 0, w, h, &kms);
+    });
+    if (st != SADHIP_OK) return st;
+    ctx->last_kernel_ms = kms;
+    ctx->last_total_ms = std::chrono::duration<float, std::milli>(clk::now() - t0).count();
+    return SADHIP_OK;
+  }
   const size_t prow = align_up((size_t)w * channels, 16);
   const size_t pcap = align_up(std::max({prow, (size_t)lstride, (size_t)rstride}) * h, 256);
   if (int st = ensure_scratch(ctx, 2 * pcap, 2 * pcap)) return st;
@@ -1307,7 +1398,11 @@ void pool_worker_main(PoolWorker* me)
       const size_t bytes = me->alloc_bytes;
       lk.unlock();
       void* p = nullptr;
-      int ast = sadhip_host_alloc(bytes, &p);
+      // the runtime places page-locked memory by the calling thread's CURRENT device (a fresh thread's is device 0): make it
+      // this worker's before the allocation -- the memset below cannot move pages that are already locked
+      int ast = SADHIP_OK;
+      if (hipSetDevice(me->ctx->device) != hipSuccess) { (void)hipGetLastError(); ast = fail(SADHIP_ERR_HIP, "hipSetDevice(%d) failed", me->ctx->device); }
+      if (ast == SADHIP_OK) ast = sadhip_host_alloc(bytes, &p);
       if (ast == SADHIP_OK) memset(p, 0, bytes);
       lk.lock();
       me->alloc_ptr = p; me->alloc_status = ast;
@@ -1422,6 +1517,14 @@ extern "C" int sadhip_pool_set_copy_threads(sadhip_pool* pool, int n)
   if (!pool) return fail(SADHIP_ERR_NULL, "pool is NULL");
   for (auto& w : pool->w)
     if (int st = sadhip_ctx_set_copy_threads(w->ctx, n)) return st;
+  return SADHIP_OK;
+}
+
+extern "C" int sadhip_pool_set_copy_spin_us(sadhip_pool* pool, int us)
+{
+  if (!pool) return fail(SADHIP_ERR_NULL, "pool is NULL");
+  for (auto& w : pool->w)
+    if (int st = sadhip_ctx_set_copy_spin_us(w->ctx, us)) return st;
   return SADHIP_OK;
 }
 

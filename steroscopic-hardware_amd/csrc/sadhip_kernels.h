@@ -42,8 +42,8 @@ void note_launch(int kind);
 int last_launch_kind();
 
 // Stream-ordered scratch (the u32 / u64 key per pixel that travels between the passes of a multi-pass job, the running-sum
-// kernel's keys): hipMallocAsync / hipFreeAsync on the job's stream, from the device's default memory pool (kernels_generic.hip
-// has the round-4 experiment with a pool of the library's own, and why it was withdrawn).
+// kernel's keys): hipMallocFromPoolAsync / hipFreeAsync on the job's stream, from one pool per device that the library owns
+// (release threshold 1 GiB: kernels_generic.hip).
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t s);
 hipError_t scratch_free(void* p, hipStream_t s);
 

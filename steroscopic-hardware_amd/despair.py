@@ -241,6 +241,17 @@ def RunSadFrame(left, right, p):
         return c.disparity(left, right, p.BlockSize, p.MaxDisparity)
 
 
+_host_gray = 0
+
+
+def SetHostGray(on):
+    """The Go shim's SetHostGray (libsadhip ABI 5, SADHIP_FLAG_HOST_GRAY): where RunSadImages / RunSadPixels convert two
+    colour pictures of one size to gray -- False (default): uploaded as they are, converted on the device; True: libsadhip's
+    copy threads write luminance rows while they stage the pictures (same integer formula, bit for bit)."""
+    global _host_gray
+    _host_gray = capi.FLAG_HOST_GRAY if on else 0
+
+
 def RunSadImages(left_pix, right_pix, p):
     """The Go shim's RunSadImages: two DECODED pictures in (HxW uint8 = *image.Gray, HxWx4 = *image.NRGBA, HxWx3 =
     opaque RGB, which Go holds as *image.RGBA with alpha 255), disparity map out, without the per-pixel
@@ -251,7 +262,7 @@ def RunSadImages(left_pix, right_pix, p):
     if left_pix.ndim == 3 and right_pix.ndim == 3 and left_pix.shape == right_pix.shape:
         h, w = left_pix.shape[:2]
         with _context(w, h) as c:
-            return c.disparity_rgba(left_pix, right_pix, p.BlockSize, p.MaxDisparity)
+            return c.disparity_rgba(left_pix, right_pix, p.BlockSize, p.MaxDisparity, _host_gray)
 
     def gray_of(pix):
         if pix.ndim == 2:
@@ -269,7 +280,7 @@ def RunSadPixels(left_pix, right_pix, blockSize, maxDisparity):
     SetDefaultParams(Parameters(BlockSize=blockSize, MaxDisparity=maxDisparity))
     h, w = left_pix.shape[:2]
     with _context(w, h) as c:
-        return c.disparity_rgba(left_pix, right_pix, blockSize, maxDisparity)
+        return c.disparity_rgba(left_pix, right_pix, blockSize, maxDisparity, _host_gray)
 
 
 def SumAbsoluteDifferences(left, right, leftX, leftY, rightX, rightY, blockSize):

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <emmintrin.h>
 #include <mutex>
+#include "gray_rows.h"
 #include <thread>
 #include <vector>
 
@@ -23,6 +24,9 @@ namespace sadhip {
 struct RowCopy {
   uint8_t* dst; size_t dpitch; const uint8_t* src; size_t spitch; size_t wbytes;
   bool whole_rows;           // the bytes between the rows may be copied too (dst is a plane of ours, src readable to its last row's wbytes)
+  // gray != 0: not a copy -- src rows are wpix pixels of `gray` (3 or 4) interleaved bytes (wbytes = wpix * gray, what is read),
+  // dst rows receive wpix luminance bytes each (gray_rows.h: the Go formula), nothing beyond them
+  int gray = 0, wpix = 0;
 };
 
 // memcpy with non-temporal stores for the 16-byte-aligned body of the destination (SSE2: every x86-64 has it).  A staged
@@ -51,6 +55,11 @@ inline void copy_stream(uint8_t* dst, const uint8_t* src, size_t n)
 inline void copy_part(const RowCopy& c, int r0, int r1)
 {
   if (r1 <= r0) return;
+  if (c.gray) {
+    for (int r = r0; r < r1; ++r) gray_row(c.dst + (size_t)r * c.dpitch, c.src + (size_t)r * c.spitch, c.wpix, c.gray);
+    _mm_sfence();
+    return;
+  }
   if (c.dpitch == c.spitch && (c.wbytes == c.dpitch || c.whole_rows)) {
     copy_stream(c.dst + (size_t)r0 * c.dpitch, c.src + (size_t)r0 * c.spitch, (size_t)(r1 - r0 - 1) * c.dpitch + c.wbytes);
   } else {
@@ -62,9 +71,12 @@ inline void copy_part(const RowCopy& c, int r0, int r1)
 class CopyGang {
  public:
   static constexpr size_t kMinBytes = (size_t)512 << 10;      // below this the calling thread copies alone
-  static constexpr int kSpinUs = 150;   // a helper polls this long for the next piece before it sleeps (L, R and the result of a
-                                        // call follow each other within that; waking a sleeping core costs 20-50 us per piece)
-  explicit CopyGang(int helpers) : helpers_(helpers) {}
+  static constexpr int kSpinUs = 150;   // default: a helper polls this long for the next piece before it sleeps (L, R and the result
+                                        // of a call follow each other within that; waking a sleeping core costs 20-50 us per piece)
+  explicit CopyGang(int helpers, int spin_us = kSpinUs) : helpers_(helpers), spin_us_(spin_us) {}
+  // how long a thread polls before it sleeps on the condition variable; 0 = sleep at once (sadhip_ctx_set_copy_spin_us)
+  void set_spin_us(int us) { spin_us_.store(us < 0 ? 0 : us, std::memory_order_relaxed); }
+  int spin_us() const { return spin_us_.load(std::memory_order_relaxed); }
   ~CopyGang()
   {
     { std::lock_guard<std::mutex> lk(mu_); stop_.store(true, std::memory_order_release); }
@@ -91,13 +103,15 @@ class CopyGang {
   }
 
  private:
-  template <class F> static bool spin_until(F&& done)
+  template <class F> bool spin_until(F&& done) const
   {
+    const int budget = spin_us_.load(std::memory_order_relaxed);
+    if (budget <= 0) return done();
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0;; ++i) {
       if (done()) return true;
       __builtin_ia32_pause();
-      if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) return false;
+      if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(budget)) return false;
     }
   }
   bool start()
@@ -143,6 +157,7 @@ class CopyGang {
   std::atomic<unsigned> gen_{0};
   std::atomic<int> pending_{0};
   std::atomic<bool> stop_{false};
+  std::atomic<int> spin_us_;
   bool failed_ = false;
 };
 

@@ -275,6 +275,9 @@ Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDis
   return RunSadImages(left, right, Parameters{blockSize, maxDisparity}, device, uploads_out);
 }
 
+static std::atomic<unsigned> g_host_gray{0};
+void SetHostGray(bool on) { g_host_gray.store(on ? SADHIP_FLAG_HOST_GRAY : 0u); }
+
 Gray RunSadImages(const Picture& left, const Picture& right, Parameters p, int device, int* uploads_out)
 {
   const int blockSize = p.BlockSize, maxDisparity = p.MaxDisparity;
@@ -286,7 +289,7 @@ Gray RunSadImages(const Picture& left, const Picture& right, Parameters p, int d
     Gray out(left.w, left.h);
     Lease ctx(dev_or_default(device), left.w, left.h);
     check(sadhip_disparity_rgba_u8(ctx.get(), left.samples.data(), right.samples.data(), left.channels, left.w, left.h,
-                                   left.w * left.channels, right.w * right.channels, blockSize, maxDisparity, 0,
+                                   left.w * left.channels, right.w * right.channels, blockSize, maxDisparity, g_host_gray.load(),
                                    out.Pix.data(), out.Stride),
           "sadhip_disparity_rgba_u8");
     note_timing(ctx.get());

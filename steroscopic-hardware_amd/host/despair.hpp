@@ -155,6 +155,10 @@ Gray RunSad(const Picture& left, const Picture& right, int blockSize, int maxDis
 // OutputCamera.processDepthMap call on the two decoded pictures instead of its color.GrayModel.Convert loops
 // (pkg/camera/output.go:142-147,157-162).
 Gray RunSadImages(const Picture& left, const Picture& right, Parameters p, int device = -1, int* uploads_out = nullptr);
+// The Go shim's SetHostGray (libsadhip ABI 5, SADHIP_FLAG_HOST_GRAY): where RunSad / RunSadImages convert two colour pictures
+// of one size to gray.  false (default): uploaded as they are, converted on the device; true: libsadhip's copy threads write
+// luminance rows while they stage the pictures (the same integer formula, bit for bit) -- a quarter of the bytes over the bus.
+void SetHostGray(bool on);
 // device / wall time of the last RunSad of the calling thread ("elapsed" of output.go:200-204)
 void LastTiming(float* kernel_ms, float* total_ms);
 

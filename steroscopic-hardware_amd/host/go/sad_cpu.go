@@ -36,6 +36,10 @@ func RunSadImages(left, right image.Image, p Parameters) *image.Gray {
 	return runSadFrameGo(GrayOf(left), GrayOf(right), p)
 }
 
+// SetHostGray is a no-op in this build (the hip build chooses between gray conversion on the device and in libsadhip's
+// copy threads; here GrayOf converts on the host either way).
+func SetHostGray(on bool) {}
+
 // NewPinnedGray is image.NewGray in this build (the hip build returns page-locked memory); free is a no-op.
 func NewPinnedGray(r image.Rectangle) (img *image.Gray, free func()) {
 	return image.NewGray(r), func() {}

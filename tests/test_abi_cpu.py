@@ -29,7 +29,55 @@ def test_library_exports_every_declared_symbol():
     l = C.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(l, name), f"{name} not exported"
-    assert capi.lib().sadhip_abi_version() == capi.ABI_VERSION == 4
+    assert capi.lib().sadhip_abi_version() == capi.ABI_VERSION == 5
+
+
+def test_host_register_contract_is_checked_before_any_lock():
+    """ABI 5 (round-4 GPU fault): sadhip_host_register locks the CALLER's pages in place, so it accepts only
+    whole 4 KiB pages of a mapping of the caller's own -- page-aligned start, length a multiple of 4096, every page mapped
+    readable + writable, nothing inside the program break ("[heap]") or a stack.  All of that is decided from /proc/self/maps
+    BEFORE the runtime is asked for anything: SADHIP_ERR_ARG with the rule in sadhip_last_error(), with or without a GPU."""
+    import mmap
+    l = capi.lib()
+    PG = 4096
+
+    def refused(addr, size, word):
+        assert l.sadhip_host_register(C.c_void_p(addr), size) == capi.ERR_ARG, (hex(addr), size)
+        assert word in l.sadhip_last_error().decode(), (word, l.sadhip_last_error())
+
+    m = mmap.mmap(-1, 64 * PG)
+    a = np.frombuffer(m, dtype=np.uint8)
+    base = a.ctypes.data
+    assert base % PG == 0
+    refused(base + 1, PG, "whole 4 KiB pages")                 # unaligned start
+    refused(base, PG + 1, "whole 4 KiB pages")                 # partial last page
+    refused(base, 100, "whole 4 KiB pages")
+    # the program break: a small malloc lives there (brk heap) -- the page around it is refused whatever its alignment
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]; libc.free.argtypes = [C.c_void_p]
+    libc.sbrk.restype = C.c_void_p; libc.sbrk.argtypes = [C.c_long]
+    brk = libc.sbrk(0)
+    heap_page = (brk - 2 * PG) & ~(PG - 1)                     # two pages below the break: inside [heap]
+    refused(heap_page, PG, "[heap]")
+    stack = [ln for ln in open("/proc/self/maps") if "[stack]" in ln]
+    if stack:
+        lo, hi = (int(v, 16) for v in stack[0].split()[0].split("-"))
+        refused(hi - 2 * PG, PG, "[stack]")
+    # a hole: one page of the mapping made inaccessible, a range across it is refused
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    assert libc.mprotect(C.c_void_p(base + 8 * PG), PG, 0) == 0
+    refused(base + 4 * PG, 8 * PG, "not mapped readable and writable")
+    assert libc.mprotect(C.c_void_p(base + 8 * PG), PG, 3) == 0
+    # beyond the end of every mapping
+    refused(0x10000, PG, "not mapped")
+    # what the contract accepts reaches the runtime: OK with a device, "no device" without one -- never ERR_ARG
+    st = l.sadhip_host_register(C.c_void_p(base), 64 * PG)
+    if _has_gpu():
+        assert st == capi.OK and l.sadhip_host_unregister(C.c_void_p(base)) == capi.OK
+    else:
+        assert st in (capi.ERR_NO_DEVICE, capi.ERR_HIP), st
+    del a
+    m.close()
 
 
 def test_status_strings():
@@ -72,6 +120,11 @@ def test_product_library_reads_no_environment():
     blob = open(capi.LIB_PATH, "rb").read()
     for name in (b"SADHIP_TUNE", b"SADHIP_PINNED_STAGING", b"SADHIP_TUNE_HOSTCOPY", b"SADHIP_BATCH_SEQ", b"NOPEN"):
         assert name not in blob, name
+    # round 5: the switch that handed pageable caller memory to the runtime (rounds 2-4's in-place path, the one the GPU memory
+    # access faults of round 4 happened on) is compiled out of the diagnostics build too
+    tune = os.path.join(os.path.dirname(capi.LIB_PATH), "libsadhip_tune.so")
+    if os.path.exists(tune):
+        assert b"SADHIP_TUNE_HOSTCOPY" not in open(tune, "rb").read()
 
 
 def test_no_column_wave_kernel_spills():
@@ -127,7 +180,6 @@ def test_abi3_entry_points_validate_and_fail_loudly_without_a_gpu():
     if not _has_gpu():
         st = l.sadhip_host_alloc(4096, C.byref(p))
         assert st in (capi.ERR_NO_DEVICE, capi.ERR_HIP) and not p.value, st
-        assert l.sadhip_host_register(junk.ctypes.data, 64) in (capi.ERR_NO_DEVICE, capi.ERR_HIP)
     geo = capi.plan_describe_batch(1920, 1080, 9, 64, 128)
     assert len(geo) == 1 and geo[0]["tiles"] == 8 and geo[0]["strips"] >= 1 and (1080 + geo[0]["rows"] - 1) // geo[0]["rows"] == geo[0]["strips"]
     assert geo[0]["device"] == (1 if _has_gpu() else 0)

@@ -874,16 +874,17 @@ def test_page_locked_host_memory_paths(ctx):
         with capi.Pool([0, 0], W, H) as pool:
             outs = pool.batch([blk[0, i] for i in range(n)], [blk[1, i] for i in range(n)], B, D, outs=[blk[2, i] for i in range(n)])
             assert all(np.array_equal(outs[i], exp[i]) for i in range(n))
-    # 7. memory the caller owns, page-locked in place
-    own = np.zeros((3, 4, H, W), np.uint8)
-    for i in range(4):
-        own[0, i], own[1, i] = pairs[i]
-    capi.host_register(own)
-    try:
+    # 7. memory the caller owns, page-locked in place: whole pages of a mapping of its own (ABI 5: the only kind accepted;
+    #    numpy's heap arrays are refused -- tests/test_abi_cpu.py::test_host_register_contract_is_checked_before_any_lock)
+    with capi.MappedBuffer(3 * 4 * H * W) as mb:
+        own = mb.view((3, 4, H, W))
+        for i in range(4):
+            own[0, i], own[1, i] = pairs[i]
         outs = ctx.disparity_batch([own[0, i] for i in range(4)], [own[1, i] for i in range(4)], B, D, outs=[own[2, i] for i in range(4)])
         assert all(np.array_equal(outs[i], exp[i]) for i in range(4))
-    finally:
-        capi.host_unregister(own)
+        del own, outs
+    heap = np.zeros(1 << 16, np.uint8)
+    assert capi.lib().sadhip_host_register(heap.ctypes.data, heap.nbytes) == capi.ERR_ARG      # unaligned and / or in the program break
     # 8. error codes, no crash: unknown pointers, double free
     l = capi.lib()
     junk = np.zeros(16, np.uint8)
@@ -955,34 +956,38 @@ def test_page_locked_batch_slot_reuse_and_failure_drains_the_streams(tmp_path):
 
 def test_host_register_refuses_overlapping_ranges():
     """the registry of page-locked ranges is sorted and DISJOINT (is_pinned looks at one predecessor, removal goes
-    by start address) -- page by page, since page-locking works on whole pages: a registration that shares a page with a
-    known range -- a sub-range of a sadhip_host_alloc block, a sub- or super-range of an earlier registration, a neighbour
-    that begins inside its last page -- is SADHIP_ERR_ARG and registers nothing.  (All ranges here are page-aligned
-    multiples of a page inside one array that outlives every registration.)"""
+    by start address): a registration that shares a page with a known range -- a sub-range of a sadhip_host_alloc block, a
+    sub- or super-range of an earlier registration, a partial overlap -- is SADHIP_ERR_ARG and registers nothing.  ABI 5:
+    registrations are whole pages of a mapping of the caller's own (here one anonymous mmap that outlives them all)."""
     import ctypes
     l = capi.lib()
     with capi.HostBuffer(1 << 20) as hb:
         base = hb.view((1 << 20,)).ctypes.data
         for off, size in ((0, 4096), (8192, 4096), ((1 << 20) - 4096, 4096)):
             assert l.sadhip_host_register(ctypes.c_void_p(base + off), size) == capi.ERR_ARG, (off, size)
-    a = np.zeros((1 << 20) + 8192, np.uint8)
-    p = (a.ctypes.data + 4095) & ~4095                                                     # page-aligned start inside a
+    import mmap
+    mm = mmap.mmap(-1, (1 << 20) + 8192)                                                   # a mapping of our own (ABI 5 accepts nothing else)
+    a = np.frombuffer(mm, dtype=np.uint8)
+    p = a.ctypes.data
     PG = 4096
+    assert p % PG == 0
     assert l.sadhip_host_register(ctypes.c_void_p(p + 16 * PG), 64 * PG) == capi.OK
-    for off, size in ((16 * PG, 64 * PG), (17 * PG, PG), (0, 32 * PG), (70 * PG, 32 * PG), (0, 200 * PG),
-                      (80 * PG - 100, PG), (15 * PG, PG + 1), (16 * PG - 1, 1 + 0)):      # the last three: only a page in common
-        expect = capi.OK if (off, size) == (16 * PG - 1, 1) else capi.ERR_ARG
-        got = l.sadhip_host_register(ctypes.c_void_p(p + off), size)
-        if (off, size) == (16 * PG - 1, 1):
-            assert got == capi.OK and l.sadhip_host_unregister(ctypes.c_void_p(p + off)) == capi.OK   # its page ends where the range begins
-        else:
-            assert got == expect, (off, size)
+    for off, size in ((16 * PG, 64 * PG), (17 * PG, PG), (0, 32 * PG), (70 * PG, 32 * PG), (0, 200 * PG), (79 * PG, 2 * PG)):
+        assert l.sadhip_host_register(ctypes.c_void_p(p + off), size) == capi.ERR_ARG, (off, size)
+        assert b"shares a page" in l.sadhip_last_error(), l.sadhip_last_error()
+    for off, size in ((80 * PG - 100, PG), (15 * PG, PG + 1), (16 * PG - 1, 1)):           # not whole pages: refused before the overlap check
+        assert l.sadhip_host_register(ctypes.c_void_p(p + off), size) == capi.ERR_ARG, (off, size)
+        assert b"whole 4 KiB pages" in l.sadhip_last_error(), l.sadhip_last_error()
+    assert l.sadhip_host_register(ctypes.c_void_p(p + 15 * PG), PG) == capi.OK             # the neighbouring page: nothing shared
+    assert l.sadhip_host_unregister(ctypes.c_void_p(p + 15 * PG)) == capi.OK
     assert l.sadhip_host_register(ctypes.c_void_p(p), 16 * PG) == capi.OK                  # adjacent pages, nothing shared
     assert l.sadhip_host_unregister(ctypes.c_void_p(p + PG)) == capi.ERR_ARG                # not the start of a range
     assert l.sadhip_host_unregister(ctypes.c_void_p(p)) == capi.OK
     assert l.sadhip_host_unregister(ctypes.c_void_p(p + 16 * PG)) == capi.OK
     assert l.sadhip_host_unregister(ctypes.c_void_p(p + 16 * PG)) == capi.ERR_ARG
-    a[:] = 1                                                                                # the array is still ours
+    a[:] = 1                                                                                # the mapping is still ours
+    del a
+    mm.close()
 
 
 def test_pool_workers_are_pinned_next_to_their_device():
@@ -1231,6 +1236,53 @@ def test_gray_and_fused_rgba(ctx, testdata_rgba, testdata_pair):
     got = sha.despair.RunSadPixels(la, ra, 9, 64)              # the Python mirror's one-call path (f-3)
     assert hashlib.sha256(got.tobytes()).hexdigest() == "0bde916590100d42d2fb6c0aca7081ba4f912c2b03a8f3bb5a8d9946454317fb"
     sha.despair.SetDefaultParams(sha.despair.Parameters(BlockSize=16, MaxDisparity=64))
+    # SADHIP_FLAG_HOST_GRAY (ABI 5): the copy threads convert while they stage -- same map, bit for bit, as the device conversion
+    got = ctx.disparity_rgba(la, ra, 7, 32, capi.FLAG_HOST_GRAY)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == "03a658082e809b4211a1216839d23a7123f1187b56f18dff0b21b6863c8a9d6e"
+    assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+    with pytest.raises(capi.SadHipError) as ei:                 # the flag belongs to the picture entry point only
+        ctx.disparity(testdata_pair[0], testdata_pair[1], 7, 32, capi.FLAG_HOST_GRAY)
+    assert ei.value.status == capi.ERR_ARG
+
+
+def test_host_gray_flag_every_alpha_class_and_layout(ctx):
+    """SADHIP_FLAG_HOST_GRAY of sadhip_disparity_rgba_u8: luminance on the host (host/gray_rows.h, vector code with an opaque
+    fast path per 8 pixels, a general-alpha path, RGB, scalar row ends) must equal oracle.gray_from_nrgba / gray_from_rgb8 bit
+    for bit, through the whole call: maps equal the oracle's on its gray planes and the device-gray call's.  Opaque, alpha in
+    251..255 (the reference's testdata), sparse and arbitrary alpha; widths around the vector width; RGB; row strides of a
+    sub-picture; raw output; a 1080p pair large enough for the copy threads to split."""
+    rng = np.random.default_rng(77)
+    cases = [(40, 64, 4, "opaque"), (37, 67, 4, "near"), (33, 131, 4, "sparse"), (25, 95, 4, "any"), (41, 70, 3, "rgb"), (30, 9, 4, "any"),
+             (30, 9, 3, "rgb"), (1080, 1920, 4, "near"), (1080, 1920, 3, "rgb")]
+    for h, w, c, kind in cases:
+        la = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        s = 5
+        ra = np.roll(la, -s, axis=1).copy()
+        ra[..., :3] ^= (rng.integers(0, 16, (h, w, 1)) == 0).astype(np.uint8)
+        if c == 4:
+            for a in (la, ra):
+                if kind == "opaque": a[..., 3] = 255
+                elif kind == "near": a[..., 3] = rng.integers(251, 256, (h, w))
+                elif kind == "sparse": a[..., 3] = np.where(rng.integers(0, 9, (h, w)) == 0, rng.integers(0, 256, (h, w)), 255)
+        gl, gr = ((oracle.gray_from_nrgba(a) if c == 4 else oracle.gray_from_rgb8(a)) for a in (la, ra))
+        B, D = (9, 64) if w >= 64 + 11 else (3, 4)
+        flags = capi.FLAG_RAW if h < 1000 else 0
+        got = ctx.disparity_rgba(la, ra, B, D, flags | capi.FLAG_HOST_GRAY)
+        dev = ctx.disparity_rgba(la, ra, B, D, flags)
+        assert np.array_equal(got, dev), (h, w, c, kind)
+        if h < 1000:
+            assert np.array_equal(got, _expect(gl, gr, B, D, raw=True)), (h, w, c, kind)
+        else:
+            assert np.array_equal(got, ctx.disparity(gl, gr, B, D)), (h, w, c, kind)
+            rows = (0, 8), (536, 544), (1072, 1080)
+            for (y0, y1), band in _literal_rows(gl, gr, B, D, rows).items():
+                assert np.array_equal(got[y0:y1], band), (kind, y0)
+    # a sub-picture: rows `stride` bytes apart inside a wider picture, nothing read outside the window's rows
+    big = rng.integers(0, 256, (50, 200, 4), dtype=np.uint8)
+    big[..., 3] = 255
+    wl, wr = big[3:43, 10:150], big[5:45, 20:160]
+    got = ctx.disparity_rgba(wl, wr, 7, 32, capi.FLAG_RAW | capi.FLAG_HOST_GRAY)
+    assert np.array_equal(got, _expect(oracle.gray_from_nrgba(np.ascontiguousarray(wl)), oracle.gray_from_nrgba(np.ascontiguousarray(wr)), 7, 32, raw=True))
 
 
 # ---- error behaviour at the boundary ------------------------------------------------------------
@@ -1363,6 +1415,58 @@ def test_batched_layout_complete_frames_vs_literal_oracle(ctx):
         L, R, o = to_host(Ls[i]), to_host(Rs[i]), to_host(out[i])
         for ya, yb in rows[:6]:
             assert np.array_equal(o[ya:yb], oracle.disparity_rows_mt(L, R, B, D, ya, yb, thr)), (i, ya, yb, passes)
+
+
+def test_config4_whole_stream_1024_pairs_one_launch(ctx):
+    """BASELINE configs[3] at its stated length, the launch bench.py times: 1024 device-resident 1920x1080 pairs (frame i =
+    seed 1000 + i, examples/run.stream.go:30-59's stream), ONE launch at 9 / 64.  Frames 0, 341, 682, 1023 complete against
+    the literal restatement; EVERY frame against the generic kernel on the device (the independent second implementation);
+    the launch's geometry is the 1024-pair plan's."""
+    import torch
+    n, W, H, B, D = 1024, 1920, 1080, 9, 64
+    parts = [sha.synth.synth_batch_torch(list(range(1000 + c, 1000 + c + 32)), W, H, "cuda:0") for c in range(0, n, 32)]
+    Ls, Rs = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]); del parts
+    out = torch.full_like(Ls, 0xCD)
+    ctx.disparity_dev(Ls, Rs, out, B, D)
+    torch.cuda.synchronize()
+    assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+    geo = capi.plan_describe_batch(W, H, B, D, n)
+    assert len(geo) == 1 and geo[0]["tiles"] == 8 and geo[0]["device"] == 1, geo
+    thr = min(16, os.cpu_count() or 1)
+    for i in (0, 341, 682, 1023):
+        L, R = to_host(Ls[i]), to_host(Rs[i])
+        if i in (0, 1023):                                         # the device generator is the host generator
+            hl, hr = sha.synth.synth_pair(1000 + i, W, H)
+            assert np.array_equal(L, hl) and np.array_equal(R, hr), i
+        assert np.array_equal(to_host(out[i]), oracle.disparity_rows_mt(L, R, B, D, 0, H, thr)), (i, geo)
+    gen = torch.full_like(Ls[:128], 0xEE)
+    for c in range(0, n, 128):                                     # 128 frames of the generic kernel at a time (0.55 s each)
+        ctx.disparity_dev(Ls[c:c + 128], Rs[c:c + 128], gen, B, D, capi.FLAG_FORCE_GENERIC)
+        torch.cuda.synchronize()
+        assert capi.last_kernel_kind() == capi.KIND_GENERIC
+        same = (out[c:c + 128] == gen).flatten(1).all(1)
+        assert bool(same.all()), (c, torch.nonzero(~same).flatten().tolist()[:8])
+
+
+def test_config5_complete_4k_frame_vs_literal_oracle(ctx):
+    """BASELINE configs[4]: ONE COMPLETE 3840x2160 frame at 15 / 128 against the literal restatement (2.4e11 byte
+    differences: a few seconds on the box's 16 host threads), single call and as frame 1 of a three-frame
+    device-resident batch (the batched launch geometry)."""
+    import torch
+    W, H, B, D = 3840, 2160, 15, 128
+    L, R = sha.synth.synth_pair(5, W, H)
+    exp = oracle.disparity_rows_mt(L, R, B, D, 0, H, min(16, os.cpu_count() or 1))
+    got = ctx.disparity(L, R, B, D)
+    assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:4]
+    L2, R2 = sha.synth.synth_pair(6, W, H)
+    Ls, Rs = to_device(np.stack([L2, L, L2])), to_device(np.stack([R2, R, R2]))
+    out = torch.full_like(Ls, 0xCD)
+    ctx.disparity_dev(Ls, Rs, out, B, D)
+    torch.cuda.synchronize()
+    o = to_host(out)
+    assert np.array_equal(o[1], exp) and np.array_equal(o[0], o[2])
+    assert np.array_equal(o[0], ctx.disparity(L2, R2, B, D))
 
 
 def test_config4_stream_shard(ctx):
