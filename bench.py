@@ -274,6 +274,20 @@ def _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, r
                                         "matches_device_resident": okp,
                                         "note": "the host thread stages every frame through the context's page-locked planes with its copy threads, three frames in flight (the cgo shim's case)"}
         legs["host_fed"]["single_call_ms"]["pageable"] = onep * 1e3
+        # ... and the call patch 0003 makes for OutputCamera (pkg/camera/output.go:134-190): two DECODED pictures in pageable memory
+        # through sadhip_disparity_rgba_u8 -- gray conversion on the device (the default: 16.6 MB over the bus) and in the copy
+        # threads while they stage (SADHIP_FLAG_HOST_GRAY, the shims' SetHostGray(true): 4.1 MB over the bus), same map
+        rng = np.random.default_rng(11)
+        pics = rng.integers(0, 256, (2, 2, H, W, 4), dtype=np.uint8); pics[..., 3] = 255      # two different opaque RGBA pairs
+        maps = {}
+        for name, fl in (("rgba_pageable_device_gray", flags), ("rgba_pageable_host_gray", flags | capi.FLAG_HOST_GRAY)):
+            for k in (0, 1):
+                maps[name] = ctx.disparity_rgba(pics[k][0], pics[k][1], block, maxdisp, fl)      # warm-up; k = 1's map is kept
+            t0 = time.perf_counter()
+            for r in range(16):
+                ctx.disparity_rgba(pics[r & 1][0], pics[r & 1][1], block, maxdisp, fl)
+            legs["host_fed"]["single_call_ms"][name] = (time.perf_counter() - t0) / 16 * 1e3
+        legs["host_fed"]["single_call_ms"]["rgba_maps_identical"] = bool(np.array_equal(maps["rgba_pageable_device_gray"], maps["rgba_pageable_host_gray"]))
         # the native pool (frame i -> device i mod G), same page-locked frames, for G = 1, 2, 4, 8 of the visible devices:
         # SURVEY 8(e) "(ii) host-fed" -- the curve that is expected to flatten at the host's PCIe / memory limit
         ndev = capi.device_count()
@@ -315,7 +329,9 @@ def _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, r
                                  "kernel_ms_sum": k_sum, "matches_device_resident": ok, "workers": placement})
         legs["pool_note"] = ("one context + host thread per device, frame i -> device i mod G, each worker thread pinned to the CPUs of its "
                              "device's NUMA node (workers[].cpus; best effort), each entry's frames in page-locked memory that worker allocated "
-                             "and first-touched: no device reads or writes across the socket link")
+                             "and first-touched after selecting its own device (the runtime places page-locked memory by the allocating thread's current device): meant to keep every "
+                             "device's reads and writes off the socket link; where the pages land is checked against the device's NUMA node on the one-GPU box "
+                             "(test_pool_workers_are_pinned_next_to_their_device), not yet on a host with devices on both sockets")
     return legs
 
 
@@ -537,6 +553,13 @@ def main():
     if world == 1 and args.host_frames > 0:
         try:
             res.update(_host_legs(sha, ctx, local, Ls, Rs, out, block, maxdisp, args.flags, min(args.host_frames, F)))
+            # the host-fed legs compare their maps with the device-resident launch's: a difference fails the run like any other
+            hf = res.get("host_fed", {})
+            wrong = [n for n, v in (("host_fed", hf.get("matches_device_resident")), ("host_fed.pageable", hf.get("pageable", {}).get("matches_device_resident")),
+                                    ("host_fed.rgba host gray vs device gray", hf.get("single_call_ms", {}).get("rgba_maps_identical")))
+                     if v is False] + [f"pool[{i}]" for i, p in enumerate(res.get("pool", [])) if p.get("matches_device_resident") is False]
+            if wrong:
+                res["parity_error"] = "host-fed result differs from the device-resident one: " + ", ".join(wrong)
         except Exception as e:                                    # side measurements never fail the headline
             res["host_fed"] = {"error": repr(e)}
 

@@ -350,8 +350,9 @@ SADHIP_API int sadhip_pool_last_timing(sadhip_pool* pool, float* kernel_ms_sum, 
  * allocated by one thread cross the socket link for half the devices of a two-socket host. */
 SADHIP_API int sadhip_pool_describe(const sadhip_pool* pool, char* buf, int cap);
 /* Page-locked memory for the frames of pool entry `entry` (frames entry, entry + G, ... of a batch), allocated AND first-touched
- * by that entry's worker thread, i.e. on the CPUs next to its device: sadhip_host_alloc semantics otherwise (usable from every
- * device; free with sadhip_host_free from any thread).  Not while a batch is running on the pool (it waits for it). */
+ * by that entry's worker thread -- pinned to the CPUs next to its device, with that device selected as the thread's current one
+ * (the runtime places page-locked memory by the allocating thread's current device); sadhip_host_alloc semantics otherwise
+ * (usable from every device; free with sadhip_host_free from any thread).  Not while a batch is running on the pool (it waits for it). */
 SADHIP_API int sadhip_pool_host_alloc(sadhip_pool* pool, int entry, size_t bytes, void** out);
 /* The same lookup for a host that drives ONE context itself (the Go shim's case): "device=<ordinal> pci=<bus id>
  * numa_node=<n or -1> cpus=<the device's local CPUs within this process's affinity mask, or ->".  A caller that pins the

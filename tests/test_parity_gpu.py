@@ -1027,6 +1027,27 @@ def test_pool_workers_are_pinned_next_to_their_device():
         with pytest.raises(capi.SadHipError) as ei:
             pool.host_alloc(2, 4096)
         assert ei.value.status == capi.ERR_ARG
+        # WHERE such memory lands.  The runtime places page-locked memory by the allocating thread's current device
+        # (the worker now selects its own before it allocates) and the thread runs on the device's CPUs: ask the kernel which
+        # node the pages are on (move_pages in its query form) and compare with the device's node -- as far as a one-GPU box
+        # can show it: both entries are device 0 here; skipped where the box hides the answer.
+        import ctypes
+        for entry in (0, 1):
+            if not (d[entry]["pinned"] and d[entry]["numa_node"] >= 0):
+                continue
+            with pool.host_alloc(entry, 64 << 20) as hb:
+                base = hb.array.ctypes.data
+                n = 64
+                pages = (ctypes.c_void_p * n)(*[base + i * (1 << 20) for i in range(n)])
+                status = (ctypes.c_int * n)(*([-1] * n))
+                libc = ctypes.CDLL(None, use_errno=True)
+                rc = libc.syscall(279, 0, ctypes.c_ulong(n), pages, None, status, 0)      # move_pages(self, n, pages, NULL, status, 0)
+                if rc != 0 or any(s < 0 for s in status):
+                    print(f"[pool placement] entry {entry}: move_pages unavailable here (rc {rc}, errno {ctypes.get_errno()}, status {sorted(set(status))})")
+                    continue
+                nodes = sorted(set(status))
+                print(f"[pool placement] entry {entry}: device node {d[entry]['numa_node']}, pages on node(s) {nodes}")
+                assert nodes == [d[entry]["numa_node"]], (entry, nodes, d[entry])
         # and the pool still computes: two contexts on the one device, frames round-robin
         L, R = sha.synth.synth_pair(77, 320, 100)
         outs = pool.batch([L] * 5, [R] * 5, 9, 32)

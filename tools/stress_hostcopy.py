@@ -2,7 +2,8 @@
 """Stress of the staged host path (round 4: caller memory that is not page-locked is copied into / out of page-locked planes
 of the context by its copy threads, in bands above 8 MB) on the GPU box.  Random frame sizes around the thresholds (the copy
 threads start at 512 KB per copy, bands at 12 MB per plane), row strides, base alignments, regions with column offsets,
-batch lengths, decoded pictures with 3 / 4 channels and a row stride, a guard page right behind the last input byte --
+batch lengths, decoded pictures with 3 / 4 channels and a row stride (device conversion and, round 5, SADHIP_FLAG_HOST_GRAY: every
+alpha class of the host conversion), a guard page right behind the last input byte --
 against the device-resident entry point on the same bytes (sadhip_disparity_dev_u8, verified by the parity tests), with
 sentinel bytes around every output window.
 usage: stress_hostcopy.py [cases] [seed]"""
@@ -78,6 +79,11 @@ def run(ncases=40, seed=0):
         else:
             ch = int(rng.choice([3, 4]))
             pic = rng.integers(0, 256, (2, h, w + padl, ch), dtype=np.uint8)
+            if ch == 4:                                               # alpha classes of the host conversion: opaque, near-opaque, sparse, arbitrary
+                amode = int(rng.integers(0, 4))
+                if amode == 0: pic[..., 3] = 255
+                elif amode == 1: pic[..., 3] = rng.integers(251, 256, pic.shape[:3])
+                elif amode == 2: pic[..., 3] = np.where(rng.integers(0, 9, pic.shape[:3]) == 0, pic[..., 3], 255)
             lp, rp = pic[0, :, offl:offl + w], pic[1, :, offl:offl + w]
             gl_, gr_ = ctx.gray(lp), ctx.gray(rp)
             want = (oracle.gray_from_nrgba if ch == 4 else oracle.gray_from_rgb8)(np.ascontiguousarray(lp))
@@ -85,6 +91,8 @@ def run(ncases=40, seed=0):
             ctx.disparity_dev(dL, dR, dO, block, D)
             torch.cuda.synchronize()
             ok = np.array_equal(gl_, want) and np.array_equal(ctx.disparity_rgba(lp, rp, block, D), to_host(dO[0]))
+            # round 5: the same pictures converted by the copy threads while they stage (SADHIP_FLAG_HOST_GRAY)
+            ok = ok and np.array_equal(ctx.disparity_rgba(lp, rp, block, D, capi.FLAG_HOST_GRAY), to_host(dO[0]))
         if not ok:
             bad += 1
             print(f"MISMATCH case {i}: {kind} {w}x{h} b{block} D{D} pads {padl},{padr},{pado} offs {offl},{offr},{offo}", flush=True)
