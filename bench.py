@@ -335,6 +335,17 @@ def _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, r
     return legs
 
 
+def _emit(res):
+    """Prints the ONE JSON line and returns the process's exit code: 3 when the line carries a parity_error (the kernel kind that ran
+    is not the planned one, a GPU frame differs from the CPU oracle, a host-fed result differs from the device-resident one) --
+    a wrong result fails the RUN the driver records, not just a JSON key -- else 0."""
+    print(json.dumps(res), flush=True)
+    if "parity_error" in res:
+        print(f"bench.py: parity_error: {res['parity_error']}", file=sys.stderr)
+        return 3
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -609,13 +620,12 @@ def main():
             "gpu_output_matches": ok}
         if not ok:
             res["parity_error"] = "a GPU frame differs from the CPU oracle"
-    print(json.dumps(res), flush=True)
+    code = _emit(res)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
-    if "parity_error" in res:                                     # a wrong kernel or a differing frame fails the RUN, not just a JSON key
-        print(f"bench.py: parity_error: {res['parity_error']}", file=sys.stderr)
-        sys.exit(3)
+    if code:
+        sys.exit(code)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ int env_int(const char* name, int dflt)
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
                                         "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE",
-                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX", "SADHIP_TUNE_TAILPCT", "SADHIP_TUNE_WARMPCT"};
+                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX", "SADHIP_TUNE_TAILPCT", "SADHIP_TUNE_WARMPCT", "SADHIP_TUNE_TAIL2"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);
@@ -221,6 +221,18 @@ long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_ro
     // vertical update -- `warm_pct` % of a row (tuning aid SADHIP_TUNE_WARMPCT)
     const double cost = t * ((double)th + (double)h2 * warm_pct / 100.0 + 4.0);
     if (cost < best * 0.999) { best = cost; best_ns = ns; }     // ties: fewer strips
+  }
+  // Kernels that fit TWO workgroups per CU (the 8-wave ones: packed h = 5..7 at wide ranges -- config 5 --, the u16-ring kernels of
+  // the reference's defaults 16 / 64) and launches of more than one round: twice the model's strips.  Measured, not modelled
+  // (round 5, profiles/r05_sweep_strips_bigwg.txt: the model's count against 1.5 / 2 / 3 / 4 times as many strips): config 5 with
+  // 4 / 8 / 16 / 32 pairs -1.8 / -4.4 / -2.4 / -2.8 % at twice the strips, B 13 D 128 -3.9 %, B 15 D 128 at 1080p -1.8 % / 0, the
+  // defaults -2.0 % / 0, B 9 D 128 -1.3 %; three and four times as many give the gain back.  Workgroups of such launches differ in
+  // length (the leftmost tile masks keys, two forms of the row loop) and with two per CU little evens that out; a tail term in the
+  // model that reproduces these optima (ideal rounds + half a workgroup) picks worse counts elsewhere (profiles/r05_ab_tail2_first.txt).
+  // The one-per-CU kernels (12 and 16 waves) measure best at the model's own count (+1 ... +4 % at twice the strips).
+  if (per_cu == 2 && env_int("SADHIP_TUNE_TAIL2", 1) != 0) {
+    const long th = (rows + best_ns - 1) / best_ns, ns0 = (rows + th - 1) / th;
+    if (base * ns0 > (long)cus * per_cu && th / 2 >= std::max<long>(min_rows, 2L * h2)) best_ns = 2 * ns0;
   }
   return best_ns;
 }

@@ -361,3 +361,19 @@ def test_block_microbenchmark_still_compiles_against_the_kernel():
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "--cuda-device-only", "-c",
                         "-Wno-unused-command-line-argument", "-o", os.devnull, src], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_bench_fails_the_run_on_a_parity_error(capsys):
+    """VERDICT r4: bench.py printed `parity_error` and exited 0.  The line is still printed (one JSON line, as the contract says);
+    the exit code is 3 whenever it carries a parity_error."""
+    import importlib.util, json
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._emit({"metric": "m", "value": 1.0}) == 0
+    assert bench._emit({"metric": "m", "value": 1.0, "parity_error": "a GPU frame differs from the CPU oracle"}) == 3
+    out = capsys.readouterr()
+    lines = [json.loads(l) for l in out.out.strip().splitlines()]
+    assert len(lines) == 2 and "parity_error" in lines[1] and "parity_error" in out.err
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert "sys.exit(code)" in src and "code = _emit(res)" in src
