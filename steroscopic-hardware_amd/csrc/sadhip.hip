@@ -196,7 +196,8 @@ static bool registrable(const void* p, size_t bytes, char* why, size_t cap)
     const char* name = name_at > 0 ? line + name_at : "";
     if (perms[0] != 'r' || perms[1] != 'w') { snprintf(why, cap, "page %p of the range is not mapped readable and writable (%s)", (void*)covered, perms); ok = false; }
     else if (!strncmp(name, "[heap]", 6) || !strncmp(name, "[stack", 6)) {
-      snprintf(why, cap, "[%p, +%zu) lies in %.7s: memory of an allocator that returns and re-takes pages under the caller cannot be page-locked in place -- use sadhip_host_alloc, or register a mapping of your own (mmap)", p, bytes, name);
+      const int nlen = (int)strcspn(name, "]\n") + 1;                     // "[heap]" / "[stack]" without the line's end
+      snprintf(why, cap, "[%p, +%zu) lies in %.*s: memory of an allocator that returns and re-takes pages under the caller cannot be page-locked in place -- use sadhip_host_alloc, or register a mapping of your own (mmap)", p, bytes, nlen, name);
       ok = false;
     }
     else covered = b;
