@@ -1,6 +1,8 @@
 // run.cpp -- counterpart of the reference's examples/run.go: load the stereo pair, RunSad with the
 // default parameters of that example (16, 64), save the disparity map.
-//   usage: run [left.png right.png [out.png [block maxdisp]]] [--frame]
+//   usage: run [left.png right.png [out.png [block maxdisp]]] [--host-gray] [--frame]
+// --host-gray: despair::SetHostGray(true) -- the gray conversion of an RGB(A) pair in libsadhip's copy threads while they
+// stage the pictures (SADHIP_FLAG_HOST_GRAY) instead of on the device; same map.
 // The decoded pictures stay in memory between decode, disparity and SavePNG: an
 // RGB(A) pair is uploaded once per image and converted to gray on the device
 // (sadhip_disparity_rgba_u8) -- no host gray plane, no $HOME/*.png round trip.  The timing line
@@ -15,6 +17,7 @@ int main(int argc, char** argv)
 {
   bool frame_mode = false;
   if (argc > 1 && std::string(argv[argc - 1]) == "--frame") { frame_mode = true; --argc; }
+  if (argc > 1 && std::string(argv[argc - 1]) == "--host-gray") { despair::SetHostGray(true); --argc; }
   const char* left = argc > 2 ? argv[1] : "./testdata/L_00001.png";     // run.go:21
   const char* right = argc > 2 ? argv[2] : "./testdata/R_00001.png";    // run.go:26
   const char* out = argc > 3 ? argv[3] : "output.png";                  // run.go:31

@@ -172,6 +172,10 @@ def test_run_frame_mode_fallback_for_pictures_of_different_formats_and_sizes(tmp
     assert r.returncode == 0 and "uploads 2)" in r.stdout, r.stdout + r.stderr
     from conftest import REAL_PAIRS
     assert hashlib.sha256(np.array(Image.open(tmp_path / "a.png")).tobytes()).hexdigest() == REAL_PAIRS["L_00002.png"]["maps"]["9/64"]["sha256"]
+    # ... and with the conversion in libsadhip's copy threads (the shims' SetHostGray(true) -> SADHIP_FLAG_HOST_GRAY): the same map
+    r = subprocess.run([run, lp, rp, str(tmp_path / "a2.png"), "9", "64", "--host-gray", "--frame"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "uploads 2)" in r.stdout, r.stdout + r.stderr
+    assert hashlib.sha256(np.array(Image.open(tmp_path / "a2.png")).tobytes()).hexdigest() == REAL_PAIRS["L_00002.png"]["maps"]["9/64"]["sha256"]
     la, ra = np.array(Image.open(lp)), np.array(Image.open(rp))
     rgb_small = np.ascontiguousarray(ra[:470, :600, :3])
     Image.fromarray(rgb_small, "RGB").save(tmp_path / "r_rgb.png")

@@ -1261,6 +1261,12 @@ def test_gray_and_fused_rgba(ctx, testdata_rgba, testdata_pair):
     got = ctx.disparity_rgba(la, ra, 7, 32, capi.FLAG_HOST_GRAY)
     assert hashlib.sha256(got.tobytes()).hexdigest() == "03a658082e809b4211a1216839d23a7123f1187b56f18dff0b21b6863c8a9d6e"
     assert capi.last_kernel_kind() == capi.KIND_COLWAVE
+    sha.despair.SetHostGray(True)                              # the shims' switch (Go: despair.SetHostGray): RunSadImages / RunSadPixels pass the flag
+    try:
+        got = sha.despair.RunSadImages(la, ra, sha.despair.Parameters(BlockSize=9, MaxDisparity=64))
+        assert hashlib.sha256(got.tobytes()).hexdigest() == "0bde916590100d42d2fb6c0aca7081ba4f912c2b03a8f3bb5a8d9946454317fb"
+    finally:
+        sha.despair.SetHostGray(False)
     with pytest.raises(capi.SadHipError) as ei:                 # the flag belongs to the picture entry point only
         ctx.disparity(testdata_pair[0], testdata_pair[1], 7, 32, capi.FLAG_HOST_GRAY)
     assert ei.value.status == capi.ERR_ARG
