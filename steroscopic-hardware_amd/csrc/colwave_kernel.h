@@ -79,10 +79,17 @@ struct CwArgs {
   const unsigned* kin;     // keys so far, or nullptr (first pass)
   unsigned* kout;          // where to leave the keys, or nullptr (last pass: write the output)
   int kw;                  // u32 per key row (= x1 - x0); key of (f, y, x) at (f*rows + y-y0)*kw + x-x0
+#ifdef SADHIP_TUNING
+  int prio_off;    // diagnostics build: 1 = no issue priority by progress (the hardware's oldest-first only), for the A/B
+#endif
 #ifdef SADHIP_STAMPS
   // stamps build only (make stamps): per-wave sums of shader-clock ticks spent in the five phases of a row
   // step (update, reduce, land, output, barrier wait) + the step count, at stamps[(workgroup*16 + wave)*8 + k]
   unsigned long long* stamps;
+  // ... and (SADHIP_TUNE_WGTL_FILE) the workgroup timeline: per workgroup {start, end in REFCLK ticks (100 MHz, one clock for the
+  // whole chip), HW_ID, XCC_ID} at wgtl[workgroup * 4 + k] -- which CU ran which workgroup when (round 5: where the resident waves
+  // that config 5 lacks go missing)
+  unsigned long long* wgtl;
 #endif
 };
 
@@ -735,6 +742,9 @@ struct Cw {                                         // P columns per lane: 4 (pa
     const int ox0 = max(tile == 0 ? j.x0 : tx + OL, j.x0);
     const int ox1 = min(tx + OL + STEP, j.x1);
     if (ys >= ye || ox0 >= ox1) return;
+#ifdef SADHIP_STAMPS
+    const unsigned long long wg_t0 = a.wgtl ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
 
     // ---- one-time setup: zero row, row-best buffers, output LUT, first ring row ----------------
     // Ring row of image row yy: L columns [tx, tx+TW) then R columns [tx-dbase-dpad, tx-dbase+TW), one u32 per
@@ -1029,6 +1039,28 @@ struct Cw {                                         // P columns per lane: 4 (pa
 #endif
     asm volatile("; SADHIP_ROWLOOP form=%c0 (tools/valu_budget.py: 3 = triple-column, 1 = plain)" :: "n"(TR3 ? 3 : 1));
     for (int t = 0; t < nsteps; ++t) {
+      // Issue priority by progress: a workgroup's waves issue with priority 3 in the first quarter of its strip, 2 / 1 / 0 in the
+      // others (s_setprio, once per 8 row steps).  The arbiter takes the highest priority first and the OLDEST wave among equals:
+      // left alone, the older of the workgroups that share a CU wins every tie -- measured with the workgroup timeline of the stamps
+      // build (profiles/r05_wg_timeline.txt): the first-dispatched workgroups of a launch finish in 0.6-0.7 of the mean duration, the
+      // later ones in 1.2 -- so the workgroups of a launch end spread over a whole duration, a launch of k rounds ends with 0.4 of a
+      // workgroup's duration of emptying chip (config 5 with 16 pairs: 12 % of the slot-time; 1080p B 9 D 64 with 128 pairs: 10 %;
+      // the 16-wave kernels, one workgroup per CU, 1 %), and short launches pay it in full.  With progress as priority the
+      // workgroups of a CU stay within a quarter strip of each other and the rounds of a launch end together: 1080p B 9 D 64 with
+      // 16 / 48 / 128 pairs -8 / -4.5 / -3.5 %, a single pair -5 %, the defaults 16 / 64 with 16 / 64 pairs -8 / -3 %, B 15, B 31, B 3,
+      // 640x480 -6 ... -8 %, config 5 -1 ... -2 %, launches of 32 rounds and the one-per-CU kernels unchanged
+      // (profiles/r05_ab_prio.txt).  Results do not depend on it.
+      // (quarters of the strip's own step count, from the loop bound: no argument, no register held for it)
+#ifdef SADHIP_TUNING
+      if (!a.prio_off)
+#endif
+      if ((t & 7) == 0) {
+        const int half = nsteps >> 1, quarter = nsteps >> 2;
+        if (t < quarter) __builtin_amdgcn_s_setprio(3);
+        else if (t < half) __builtin_amdgcn_s_setprio(2);
+        else if (t < half + quarter) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
       if constexpr (RECOMPUTE_SHARE) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -1091,6 +1123,12 @@ struct Cw {                                         // P columns per lane: 4 (pa
     }
     finalize(nsteps - 1);
 #ifdef SADHIP_STAMPS
+    if (a.wgtl && tid == 0) {
+      unsigned long long* o = a.wgtl + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4;
+      o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime();
+      o[2] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID, all 32 bits
+      o[3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+    }
     if (a.stamps && lane == 0) {
       unsigned long long* o = a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wv) * 8;
       for (int k = 0; k < 5; ++k) o[k] = st_sum[k];

@@ -24,7 +24,7 @@ int env_int(const char* name, int dflt)
                                         "SADHIP_TUNE_CHUNK", "SADHIP_TUNE_WGS", "SADHIP_TUNE_ROWS",
                                         "SADHIP_TUNE_WGMAX", "SADHIP_TUNE_LDSPAD", "SADHIP_TUNE_WB", "SADHIP_TUNE_VERBOSE",
                                         "SADHIP_TUNE_STAMPS", "SADHIP_TUNE_LEGACY_STRIPS", "SADHIP_TUNE_STRIPS", "SADHIP_TUNE_MINROWS", "SADHIP_TUNE_TRMIN", "SADHIP_TUNE_TRMODE",
-                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX", "SADHIP_TUNE_TAILPCT", "SADHIP_TUNE_WARMPCT", "SADHIP_TUNE_TAIL2"};
+                                        "SADHIP_TUNE_W16NW", "SADHIP_TUNE_W16ND4", "SADHIP_TUNE_MIX", "SADHIP_TUNE_TAILPCT", "SADHIP_TUNE_WARMPCT", "SADHIP_TUNE_TAIL2", "SADHIP_TUNE_PRIO"};
     std::vector<Entry> t;
     for (const char* n : names) {
       const char* e = getenv(n);

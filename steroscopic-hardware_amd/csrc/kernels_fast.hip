@@ -122,6 +122,9 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   if (nstrips < 1) nstrips = 1;
   a.th = (int)((rows + nstrips - 1) / nstrips);
   nstrips = (rows + a.th - 1) / a.th;
+#ifdef SADHIP_TUNING
+  a.prio_off = env_int("SADHIP_TUNE_PRIO", 1) ? 0 : 1;          // issue priority by progress (colwave_kernel.h, the row loop): on unless SADHIP_TUNE_PRIO=0
+#endif
   if (geom) { geom->tiles = ntiles; geom->strips = (int)nstrips; geom->rows = a.th; geom->per_cu = per_cu; geom->device = asked; return hipSuccess; }
   if (env_int("SADHIP_TUNE_VERBOSE", 0))
     fprintf(stderr, "sadhip: P%d ND%d H%d nw%d: %ld strips of %d rows x %ld workgroups per layer, %d per CU, lds %zu\n", P, ND, H, pl.nw, nstrips, a.th,
@@ -143,11 +146,33 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
       if (hipMalloc((void**)&aa.stamps, nwg * 16 * 8 * sizeof(unsigned long long)) != hipSuccess) aa.stamps = nullptr;
       else (void)hipMemsetAsync(aa.stamps, 0, nwg * 16 * 8 * sizeof(unsigned long long), s);
     }
+    aa.wgtl = nullptr;
+    const char* wgtl_file = getenv("SADHIP_TUNE_WGTL_FILE");        // workgroup timeline of every launch, appended as CSV
+    if (wgtl_file) {
+      if (hipMalloc((void**)&aa.wgtl, nwg * 4 * sizeof(unsigned long long)) != hipSuccess) aa.wgtl = nullptr;
+      else (void)hipMemsetAsync(aa.wgtl, 0, nwg * 4 * sizeof(unsigned long long), s);
+    }
 #endif
     hipLaunchKernelGGL((k_colwave<P, ND, H, PK, WB, W16, TR, MIX>), dim3((unsigned)(nstrips * aa.j.n), ntiles, 1), dim3(64 * pl.nw), lds, s, aa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef SADHIP_STAMPS
+    if (aa.wgtl) {
+      (void)hipStreamSynchronize(s);
+      std::vector<unsigned long long> h(nwg * 4);
+      (void)hipMemcpy(h.data(), aa.wgtl, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      (void)hipFree(aa.wgtl);
+      static int launch_no = 0;
+      if (FILE* f = fopen(wgtl_file, "a")) {
+        if (launch_no == 0) fprintf(f, "launch,p,nd,h,nw,strips,rows,frames,tiles,x,y,t0,t1,hw_id,xcc_id\n");
+        const unsigned gx = (unsigned)(nstrips * aa.j.n);
+        for (size_t g = 0; g < nwg; ++g)
+          fprintf(f, "%d,%d,%d,%d,%d,%ld,%d,%d,%d,%u,%u,%llu,%llu,%llu,%llu\n", launch_no, P, ND, H, pl.nw, nstrips, a.th, aa.j.n, ntiles, (unsigned)(g % gx), (unsigned)(g / gx),
+                  h[4 * g], h[4 * g + 1], h[4 * g + 2], h[4 * g + 3]);
+        fclose(f);
+      }
+      ++launch_no;
+    }
     if (aa.stamps) {                                      // average ticks per row step and phase, by wave class
       (void)hipStreamSynchronize(s);
       std::vector<unsigned long long> h(nwg * 16 * 8);

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round 5 experiment: issue priority by progress (SADHIP_TUNE_PRIO=1, tuning build) against the hardware's oldest-first.  us per pair.
+cd "$(dirname "$0")/../.."
+for c in "3840 2160 15 128 16" "3840 2160 15 128 32" "3840 2160 15 128 8" "3840 2160 15 128 1" "1920 1080 9 64 1" "1920 1080 9 64 16" "1920 1080 9 64 48" "1920 1080 9 64 128" "1920 1080 9 64 1024" "1920 1080 16 64 1" "1920 1080 16 64 16" "1920 1080 16 64 64" \
+         "1920 1080 15 64 64" "1920 1080 13 128 32" "1920 1080 16 128 64" "1920 1080 3 16 64" "640 480 7 32 128" "1920 1080 31 64 16" \
+         "1920 1080 13 112 32" "1920 1080 9 112 32" "1920 1080 15 80 32" "1920 1080 16 48 32" "1920 1080 21 96 32" "1920 1080 11 144 16" "1920 1080 9 176 16" "1920 1080 16 256 16" "1280 720 9 64 8" "640 480 16 64 1" "640 480 7 32 1"; do
+  line="$c :"
+  for t in 0 1 0 1; do
+    v=$(SADHIP_TUNE_PRIO=$t timeout -k 10 100 python tools/bench_cfg.py $c 2>/dev/null | grep us/frame | sed 's/.*kind=1: \([0-9.]*\) us.*parity=\(.*\)/\1 \2/')
+    line="$line  prio=$t $v"
+  done
+  echo "$line"
+done
