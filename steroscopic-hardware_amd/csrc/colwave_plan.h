@@ -40,7 +40,8 @@ Plan plan_count(int h, bool pk, int count, bool exact, int maxdisp);
 // caller streams frames with the same parameters): the reference stays valid until the thread plans other parameters.
 const std::vector<Pass>& plan_job(int h, int maxdisp, bool narrow);
 // Strips per frame of a launch (cost model in colwave_plan.hip).
-long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_rows);
+// uneven: the kernel's workgroups differ in length by tile (packed h = 6, 7: key masks / two forms of the row loop)
+long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_rows, bool uneven);
 int cu_count();
 
 }  // namespace sadhip

@@ -200,7 +200,7 @@ static std::vector<Pass> plan_job_uncached(int h, int maxdisp, bool narrow)
 //   leftmost tiles mask keys, CUs differ), and the longer they are the longer the chip waits for the last
 //   one (measured: 128 1080p pairs as 1 / 4 strips 27.7 / 24.2 us per pair; config 5 with 16 pairs as
 //   1 / 2 / 4 / 6 rounds 228 / 218 / 213 / 210)
-long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_rows)
+long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_rows, bool uneven)
 {
   const long max_strips = std::max<long>(1, (rows + min_rows - 1) / min_rows);
   const double slots = (double)cus * per_cu;
@@ -222,15 +222,16 @@ long choose_strips(long base, long rows, int h2, int cus, int per_cu, int min_ro
     const double cost = t * ((double)th + (double)h2 * warm_pct / 100.0 + 4.0);
     if (cost < best * 0.999) { best = cost; best_ns = ns; }     // ties: fewer strips
   }
-  // Kernels that fit TWO workgroups per CU (the 8-wave ones: packed h = 5..7 at wide ranges -- config 5 --, the u16-ring kernels of
-  // the reference's defaults 16 / 64) and launches of more than one round: twice the model's strips.  Measured, not modelled
-  // (round 5, profiles/r05_sweep_strips_bigwg.txt: the model's count against 1.5 / 2 / 3 / 4 times as many strips): config 5 with
-  // 4 / 8 / 16 / 32 pairs -1.8 / -4.4 / -2.4 / -2.8 % at twice the strips, B 13 D 128 -3.9 %, B 15 D 128 at 1080p -1.8 % / 0, the
-  // defaults -2.0 % / 0, B 9 D 128 -1.3 %; three and four times as many give the gain back.  Workgroups of such launches differ in
-  // length (the leftmost tile masks keys, two forms of the row loop) and with two per CU little evens that out; a tail term in the
-  // model that reproduces these optima (ideal rounds + half a workgroup) picks worse counts elsewhere (profiles/r05_ab_tail2_first.txt).
-  // The one-per-CU kernels (12 and 16 waves) measure best at the model's own count (+1 ... +4 % at twice the strips).
-  if (per_cu == 2 && env_int("SADHIP_TUNE_TAIL2", 1) != 0) {
+  // Kernels that fit TWO workgroups per CU and whose workgroups differ in length by tile (`uneven`: the packed h = 6, 7 kernels -- the
+  // leftmost tiles mask keys and, for h = 7, run the plain form of the row loop while the others run the triple-column one): twice
+  // the model's strips on launches of more than one round.  Measured, not modelled (round 5).  First for every two-per-CU kernel
+  // (profiles/r05_sweep_strips_bigwg.txt, r05_ab_strips_x2.txt: config 5 with 4 / 8 / 16 / 32 pairs -1.7 / -3.3 / -2.2 / -2.6 %,
+  // B 13 D 128 -2.6 %, the defaults 16 / 64 -1 ... -2 %); then again with the issue priority by progress in the kernel (colwave_kernel.h),
+  // which took the spread out of equal workgroups' durations (profiles/r05_ab_strips_x2_with_priority.txt): config 5 still -0.6 /
+  // -2.2 / -2.9 / -1.4 %, B 13 D 128 -2.6 %, but the defaults (+0.6 %) and B 9 D 128 (+1.3 %), whose tiles are all alike, no longer
+  // want it.  A tail term in the model that reproduces the first sweep's optima (ideal rounds + half a workgroup) picked worse
+  // counts elsewhere (profiles/r05_ab_tail2_first.txt).  The one-per-CU kernels (12 and 16 waves) measure best at the model's count.
+  if (per_cu == 2 && uneven && env_int("SADHIP_TUNE_TAIL2", 1) != 0) {
     const long th = (rows + best_ns - 1) / best_ns, ns0 = (rows + th - 1) / th;
     if (base * ns0 > (long)cus * per_cu && th / 2 >= std::max<long>(min_rows, 2L * h2)) best_ns = 2 * ns0;
   }

@@ -115,7 +115,7 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   } else if (env_int("SADHIP_TUNE_STRIPS", 0) > 0) {
     nstrips = env_int("SADHIP_TUNE_STRIPS", 0);
   } else {
-    nstrips = choose_strips(base, rows, 2 * H, cu_count(), per_cu, min_rows);
+    nstrips = choose_strips(base, rows, 2 * H, cu_count(), per_cu, min_rows, PK && H > 5);
   }
   const long max_strips = (rows + min_rows - 1) / min_rows;
   if (nstrips > max_strips) nstrips = max_strips;
