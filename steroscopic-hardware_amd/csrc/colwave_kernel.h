@@ -709,6 +709,11 @@ struct Cw {                                         // P columns per lane: 4 (pa
   // wv0 / dcl0: first wave of this wave's group and the group's first candidate within the pass (0, 0 unless the kernel
   // mixes two chunk sizes: there the waves [nwa, nw) run Cw<P, NDB, ...>::run(a, nwa, nwa*ND) on the SAME ring, row
   // buffers and barriers -- every quantity of the LDS layout below depends on a.slots / a.nw, none on ND)
+  // PRIO: issue priority by progress (the row loop's head).  Off in the mixed-chunk kernels: their waves are of two kinds, the
+  // heavier chunk's waves are the older ones and the arbiter's oldest-first is what keeps them -- the row step's critical path --
+  // ahead; with the priority updates the 12- and 16-wave mixed kernels measured 3-6 % SLOWER (B 16 D 80 46.6 -> 49.6 us, D 112
+  // 58.5 -> 62.2; packed B 13 D 80 37.2 -> 38.6), every uniform kernel faster or equal.
+  template <bool PRIO = true>
   static __device__ __forceinline__ void run(const CwArgs& a, const int wv0 = 0, const int dcl0 = 0)
   {
     extern __shared__ __attribute__((aligned(16))) unsigned smem[];
@@ -1054,7 +1059,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
 #ifdef SADHIP_TUNING
       if (!a.prio_off)
 #endif
-      if ((t & 7) == 0) {
+      if (PRIO && (t & 7) == 0) {
         const int half = nsteps >> 1, quarter = nsteps >> 2;
         if (t < quarter) __builtin_amdgcn_s_setprio(3);
         else if (t < half) __builtin_amdgcn_s_setprio(2);
@@ -1152,7 +1157,7 @@ struct Cw {                                         // P columns per lane: 4 (pa
 template <int P, int ND, bool PK> struct MixChunk { static constexpr int NDB = PK ? ND - 4 : ND / 2; };
 
 // One wave group of a kernel: picks the form (TR: per workgroup, see k_colwave) and runs it.
-template <int P, int ND, int H, bool PK, bool W16, bool TR>
+template <int P, int ND, int H, bool PK, bool W16, bool TR, bool PRIO = true>
 __device__ __forceinline__ void run_group(const CwArgs& a, int wv0, int dcl0)
 {
   if constexpr (TR) {
@@ -1167,9 +1172,9 @@ __device__ __forceinline__ void run_group(const CwArgs& a, int wv0, int dcl0)
       const int ox0 = max(tile == 0 ? a.j.x0 : tx + K::OL, a.j.x0);
       triple = triple && !(max(ox0, 0) - H < min(a.dbase + a.slots, a.j.maxdisp));
     }
-    if (triple) K::run(a, wv0, dcl0); else Cw<P, ND, H, PK, W16, false>::run(a, wv0, dcl0);
+    if (triple) K::template run<PRIO>(a, wv0, dcl0); else Cw<P, ND, H, PK, W16, false>::template run<PRIO>(a, wv0, dcl0);
   } else {
-    Cw<P, ND, H, PK, W16, false>::run(a, wv0, dcl0);
+    Cw<P, ND, H, PK, W16, false>::template run<PRIO>(a, wv0, dcl0);
   }
 }
 
@@ -1183,8 +1188,8 @@ __global__ void __launch_bounds__(WB) k_colwave(CwArgs a)
     static_assert((W16 && !PK && ND == 8 && !TR) || (PK && P == 4 && !W16 && ND >= 8),
                   "mixed chunks: unpacked on the u16 ring (8 + 4), or packed P = 4 (ND, ND - 4)");
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wv < a.nwa) run_group<P, ND, H, PK, W16, TR>(a, 0, 0);
-    else run_group<P, MixChunk<P, ND, PK>::NDB, H, PK, W16, TR>(a, a.nwa, a.nwa * ND);
+    if (wv < a.nwa) run_group<P, ND, H, PK, W16, TR, false>(a, 0, 0);
+    else run_group<P, MixChunk<P, ND, PK>::NDB, H, PK, W16, TR, false>(a, a.nwa, a.nwa * ND);
   } else {
     run_group<P, ND, H, PK, W16, TR>(a, 0, 0);
   }
