@@ -102,11 +102,17 @@ hipError_t launch_t(const Job& j, const Plan& pl, const PassIo& io, hipStream_t 
   // choose_strips() minimises a small cost model over the possible strip counts, with the number of
   // workgroups of THIS kernel a CU holds asked from the runtime (registers, LDS, waves).
   const long base = (long)ntiles * j.n;
-  // shortest strip: 8 rows (single small frames: 640x480 28.8 -> 26.7 us, 1280x720 B9 47.1 -> 38.5; no change at 1080p)
-  const int min_rows = env_int("SADHIP_TUNE_MINROWS", 8);
   long nstrips;
   bool asked = false;
   const int per_cu = wgs_per_cu(k_colwave<P, ND, H, PK, WB, W16, TR, MIX>, 64 * pl.nw, lds, &asked);
+  // shortest strip: 8 rows (single small frames: 640x480 28.8 -> 26.7 us, 1280x720 B9 47.1 -> 38.5; no change at 1080p) -- and 4
+  // rows for launches so small that even 4-row strips do not fill the chip's workgroup slots (round 5: one 640x480 pair, the
+  // WebUI's own frame size, at the defaults 16 / 64 is 120 workgroups on 120 of 256 CUs with 8-row strips, each doing 8 output
+  // rows in 28 row steps: 44.2 -> 34.0 us with 4-row strips; 640x480 7 / 32 22.5 -> 19.0, 9 / 64 27.2 -> 24.3, 320x240 42 -> 32;
+  // launches that 4-row strips would push past one round keep 8 -- 1280x720 16 / 64 measured 5 % worse with 4;
+  // profiles/r05_ab_minrows.txt)
+  int min_rows = env_int("SADHIP_TUNE_MINROWS", 0);
+  if (min_rows <= 0) min_rows = base * ((rows + 3) / 4) <= (long)cu_count() * per_cu ? 4 : 8;
   if (env_int("SADHIP_TUNE_LEGACY_STRIPS", 0)) {                // round 2's constants, for comparison
     const long want = env_int("SADHIP_TUNE_WGS", P == 4 ? 512 : 256);
     const long rows_target = env_int("SADHIP_TUNE_ROWS", 48 * H), wg_max = env_int("SADHIP_TUNE_WGMAX", 4096);
