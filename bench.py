@@ -288,6 +288,24 @@ def _host_legs_pinned(sha, ctx, local, Ls, Rs, out, block, maxdisp, flags, nf, r
                 ctx.disparity_rgba(pics[r & 1][0], pics[r & 1][1], block, maxdisp, fl)
             legs["host_fed"]["single_call_ms"][name] = (time.perf_counter() - t0) / 16 * 1e3
         legs["host_fed"]["single_call_ms"]["rgba_maps_identical"] = bool(np.array_equal(maps["rgba_pageable_device_gray"], maps["rgba_pageable_host_gray"]))
+        # ... and the reference's OWN frames: testdata/ holds 640x480 pictures and params.go:13-18 starts the UI at 16 / 64 -- one
+        # synchronous call per pair from pageable memory at that size (gray pair; RGBA pair converted on the device / in the copy threads)
+        sw, sh_, sb, sd = 640, 480, 16, 64
+        with capi.Context(local, sw, sh_, 1) as small:
+            sp = [sha.synth.synth_pair(4000 + k, sw, sh_) for k in range(4)]
+            spic = rng.integers(0, 256, (2, 2, sh_, sw, 4), dtype=np.uint8); spic[..., 3] = 255
+            webui = {"frame": f"{sw}x{sh_}", "block": sb, "maxdisp": sd}
+            for name, fn in (("gray_pageable", lambda k: small.disparity(sp[k & 3][0], sp[k & 3][1], sb, sd)),
+                             ("rgba_pageable_device_gray", lambda k: small.disparity_rgba(spic[k & 1][0], spic[k & 1][1], sb, sd)),
+                             ("rgba_pageable_host_gray", lambda k: small.disparity_rgba(spic[k & 1][0], spic[k & 1][1], sb, sd, capi.FLAG_HOST_GRAY))):
+                for k in range(4):
+                    fn(k)
+                t0 = time.perf_counter()
+                for k in range(32):
+                    fn(k)
+                webui[name] = (time.perf_counter() - t0) / 32 * 1e3
+            webui["kernel"] = small.last_timing()[0]
+        legs["host_fed"]["single_call_ms"]["reference_frame_size_640x480_defaults"] = webui
         # the native pool (frame i -> device i mod G), same page-locked frames, for G = 1, 2, 4, 8 of the visible devices:
         # SURVEY 8(e) "(ii) host-fed" -- the curve that is expected to flatten at the host's PCIe / memory limit
         ndev = capi.device_count()
