@@ -674,7 +674,10 @@ static int enqueue_frame(sadhip_ctx* c, Slot& s, const uint8_t* left, const uint
   } else {
     if (int st = ensure_stage(c, s)) return st;
     const int lrows = band1 - band0, rrows = rband1 - band0;
-    if (s.up != s.stream && c->pair_upload && rrows > 0 && band_count(lrows, pitch, c->band_bytes) == 1 &&
+    // (round 5) ... unless the pair is small: below 1 MiB for both planes the second copy's fixed cost (~10 us) is more than the
+    // overlap of the left plane's transfer with the right plane's staging is worth -- the reference's own frames are 640x480
+    const bool small_pair = (size_t)(lrows + rrows) * pitch <= ((size_t)1 << 20);
+    if ((s.up != s.stream || small_pair) && c->pair_upload && rrows > 0 && band_count(lrows, pitch, c->band_bytes) == 1 &&
         band_count(rrows, pitch, c->band_bytes) == 1) {
       // a frame of a batch: the right rows right behind the left ones, the pair as ONE upload -- a 2.2 MB copy costs 54 us of
       // which ~10 are fixed, and two of them per pair were the upload stream's limit (9 100 pairs/s at 1080p).  Not for a
