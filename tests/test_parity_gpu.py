@@ -1046,8 +1046,15 @@ def test_pool_workers_are_pinned_next_to_their_device():
                     print(f"[pool placement] entry {entry}: move_pages unavailable here (rc {rc}, errno {ctypes.get_errno()}, status {sorted(set(status))})")
                     continue
                 nodes = sorted(set(status))
-                print(f"[pool placement] entry {entry}: device node {d[entry]['numa_node']}, pages on node(s) {nodes}")
-                assert nodes == [d[entry]["numa_node"]], (entry, nodes, d[entry])
+                allowed = set()
+                for ln in open("/proc/self/status"):
+                    if ln.startswith("Mems_allowed_list:"):
+                        for part in ln.split(":", 1)[1].strip().split(","):
+                            a_, _, b_ = part.partition("-")
+                            allowed.update(range(int(a_), int(b_ or a_) + 1))
+                print(f"[pool placement] entry {entry}: device node {d[entry]['numa_node']}, pages on node(s) {nodes}, memory nodes this process may use {sorted(allowed)}")
+                if d[entry]["numa_node"] in allowed:              # (a cgroup that keeps this process off the device's node decides otherwise)
+                    assert nodes == [d[entry]["numa_node"]], (entry, nodes, d[entry])
         # and the pool still computes: two contexts on the one device, frames round-robin
         L, R = sha.synth.synth_pair(77, 320, 100)
         outs = pool.batch([L] * 5, [R] * 5, 9, 32)
