@@ -79,7 +79,8 @@ def test_real_inputs_complete_frames(ctx, name, key):
     live (up to 130 000 zero-disparity pixels per map); the synthetic generator avoids them on purpose.  COMPLETE maps:
     (1) equal to the literal restatement of sad.go:55-94 run here, (2) equal to the digest pinned in the build
     container (tests/golden/real_pairs.json), (3) the generic kernel agrees, (4) 1080p: the same map as frames 0 and n-1 of
-    a device-resident batch (the batched launch geometry: few tall strips), (5) the fused RGB(A) entry (device gray)."""
+    a device-resident batch (the batched launch geometry: few tall strips), (5) the fused RGB(A) entry (device gray), (6) the
+    same entry with the conversion in the copy threads (SADHIP_FLAG_HOST_GRAY)."""
     import torch
     e = REAL_PAIRS[name]
     b, d = map(int, key.split("/"))
@@ -95,6 +96,9 @@ def test_real_inputs_complete_frames(ctx, name, key):
     assert np.array_equal(ctx.disparity(L, R, b, d, capi.FLAG_FORCE_GENERIC), exp)
     fused = ctx.disparity_rgba(load_real_pixels(e["left"]), load_real_pixels(e["right"]), b, d)
     assert np.array_equal(fused, exp), (name, key, "fused gray + disparity")
+    # (6) the same pictures with the gray conversion in the copy threads (SADHIP_FLAG_HOST_GRAY, ABI 5): real alpha 251..255
+    hostg = ctx.disparity_rgba(load_real_pixels(e["left"]), load_real_pixels(e["right"]), b, d, capi.FLAG_HOST_GRAY)
+    assert np.array_equal(hostg, exp), (name, key, "host gray + disparity")
     # device-resident batch: the real pair first and last, synthetic frames (or the other real pairs) between
     n = 12 if w == 1920 else 40
     mid = [sha.synth.synth_pair(4000 + i, w, h) for i in range(3)]
