@@ -1455,6 +1455,37 @@ def test_batched_layout_complete_frames_vs_literal_oracle(ctx):
             assert np.array_equal(o[ya:yb], oracle.disparity_rows_mt(L, R, B, D, ya, yb, thr)), (i, ya, yb, passes)
 
 
+def test_small_single_frames_run_short_strips_and_stay_exact(ctx):
+    """Round 5: a launch that even 4-row strips cannot spread over all workgroup slots of its kernel gets strips down to 4 rows
+    (kernels_fast.hip; one 640x480 pair -- the reference's own frame size -- at its defaults 16 / 64 was 120 workgroups on 120 of
+    256 CUs with the 8-row floor).  Complete frames against the oracle for the sizes and parameters where the rule acts, the
+    geometry the library reports (rows per strip < 8 there, >= 8 for a launch that fills the chip), and the same frames as part
+    of a batch (which keeps the taller strips)."""
+    import torch
+    short = 0
+    for (w, h) in ((640, 480), (320, 240), (200, 100)):
+        for (b, d) in ((16, 64), (7, 32), (9, 64), (3, 16), (21, 96), (31, 64), (15, 128)):
+            if w <= d + 2 * (b // 2) + 2 and b < 6:
+                continue
+            L, R = sha.synth.synth_pair(9000 + w + b + d, w, h)
+            exp = _expect(L, R, b, d)
+            got = ctx.disparity(L, R, b, d)
+            assert np.array_equal(got, exp), (w, h, b, d)
+            if capi.last_kernel_kind() != capi.KIND_COLWAVE:
+                continue
+            geo = capi.plan_describe_batch(w, h, b, d, 1)
+            assert all(g["device"] == 1 and g["rows"] >= 4 for g in geo), geo
+            short += any(g["rows"] < 8 for g in geo)
+            Ls, Rs = to_device(np.stack([L] * 3)), to_device(np.stack([R] * 3))
+            out = torch.empty_like(Ls)
+            ctx.disparity_dev(Ls, Rs, out, b, d)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(out[1]), exp), (w, h, b, d, "batch of 3")
+    assert short >= 8, short                                    # the rule acted (640x480 at 16 / 64 and 7 / 32 among them)
+    big = capi.plan_describe_batch(1920, 1080, 9, 64, 128)
+    assert all(g["rows"] >= 8 for g in big), big
+
+
 def test_config4_whole_stream_1024_pairs_one_launch(ctx):
     """BASELINE configs[3] at its stated length, the launch bench.py times: 1024 device-resident 1920x1080 pairs (frame i =
     seed 1000 + i, examples/run.stream.go:30-59's stream), ONE launch at 9 / 64.  Frames 0, 341, 682, 1023 complete against
